@@ -1,0 +1,130 @@
+/*
+ * oracle/orc.h -- CPU restatement of the reference's volumetric path-tracing hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load liborc.so, and there only as the checker /
+ * reported baseline.  The product (libclwhip.so) never links or calls anything here.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - SDF builder (orc_sdf_build): PINNED bit-exactly by the reference's own golden vector
+ *     tests/sdf/values.x for tests/sdf/testdata.nrrd  (tests/test_oracle_sdf.py).
+ *   - render / compute_light / RNG / cut / env lookup / voxel cache: PARITY UNPINNED --
+ *     the reference holds no golden image or known-answer vector for them and its OpenCL
+ *     kernels cannot run in this image (no OpenCL CPU runtime).  Every function cites the
+ *     reference file:line it restates so the restatement can be audited by reading.
+ *
+ * Implementation-defined OpenCL behaviour is fixed as follows (DESIGN.md "Semantics"):
+ *   - integer images + CLK_FILTER_LINEAR  -> nearest: texel = floor(coord), out of range
+ *     (or NaN) -> border 0 for CLK_ADDRESS_CLAMP; env map: floor(u*w) clamped to edge.
+ *   - no FMA contraction anywhere; every float op is a single IEEE-754 binary32 operation
+ *     in the order written.
+ *   - normalize(v) = v / sqrtf((v.x*v.x + v.y*v.y) + v.z*v.z)  (three IEEE divisions).
+ *   - atan2, asin, pow: correctly rounded binary32 results, obtained by evaluating in
+ *     binary64 and rounding once.
+ *   - float -> int / uint conversions truncate toward zero, saturate, NaN -> 0.
+ *   - min(a,b) = (b < a) ? b : a ;  max(a,b) = (a < b) ? b : a.
+ */
+#ifndef ORC_H
+#define ORC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_TF_MAX_RULES 16
+
+/* One transfer-function rule:  value in [v_lo, v_hi]  (&& gradient in [g_lo, g_hi] if use_gradient).
+ * The reference builds OpenCL-C source (app/ui.cpp:160-168, app/tf_part.cpp:55-79); comparing a
+ * short against printed decimal literals is a comparison of integers against reals, so the
+ * thresholds are pre-rounded to the equivalent inclusive integer bounds by the caller. */
+typedef struct {
+  int32_t v_lo, v_hi;
+  int32_t g_lo, g_hi;
+  int32_t use_gradient;   /* rule reads `gradient` */
+  int32_t writes_color;   /* rule assigns *color (rectangle form) or not (`return (value > 800);`) */
+  int32_t terminal;       /* `return (cond);` form: evaluation stops here whether or not it matched */
+  int32_t color[4];       /* r,g,b,a(=roughness) in 0..255 */
+} orc_tf_rule;
+
+typedef struct {
+  int32_t n;
+  orc_tf_rule rules[ORC_TF_MAX_RULES];
+} orc_tf;
+
+/* counters[]: exact texel / atomic counts for the algorithmic-bytes model */
+enum {
+  ORC_N_SDF = 0,   /* SDF texel fetches (1 B each) */
+  ORC_N_VOL = 1,   /* volume texel fetches (2 B each) */
+  ORC_N_ENV = 2,   /* env texel fetches (4 B each) */
+  ORC_N_TOK = 3,   /* token atomics (4 B RMW each; the undo sub counts too) */
+  ORC_N_ADD = 4,   /* cache adds (2 x 4 B) */
+  ORC_N_READ = 5,  /* cache reads (8 B) */
+  ORC_N_HIT = 6,   /* pixel-samples whose primary march ended in Hit */
+  ORC_N_STEP = 7,  /* march steps */
+  ORC_N_COUNTERS = 8
+};
+
+enum { ORC_MODE_VOXEL_CACHE = 0, ORC_MODE_IMAGE_SPACE = 1 };
+
+typedef struct {
+  const int16_t *volume;      /* x-fastest [z][y][x] */
+  int32_t X, Y, Z;
+  const int8_t *sdf;          /* same layout */
+  const uint8_t *env;         /* RGBA8, row-major */
+  int32_t env_w, env_h;
+  uint16_t *cache;            /* voxel cache, orc_cache_len(X,Y,Z) ushorts */
+  uint8_t *frame;             /* RGBA8 frame image, frame_w x frame_h */
+  int32_t frame_w, frame_h;   /* image dims (what get_image_width(frame) returns) */
+  int32_t launch_w, launch_h; /* NDRange global size */
+  float cam_pos[3];
+  float cam_dir[3];
+  int32_t seed;
+  const orc_tf *tf;
+  int32_t mode;
+  float *accum;               /* image-space mode: float4 per pixel {r,g,b,count} */
+  int64_t *hit_index;         /* optional, per pixel: cache entry index (voxel units) or -1 */
+  uint32_t *contrib;          /* optional, per pixel: {r,g,b,granted} of this pass */
+  uint64_t *counters;         /* optional, ORC_N_COUNTERS totals, accumulated */
+  int32_t tile_rank, tile_world; /* image-tile partition: 8x8 tiles, owner = (tx+ty) % world */
+  int32_t threads;            /* OpenMP threads (1 = deterministic sequential pixel order) */
+} orc_render_params;
+
+/* number of ushorts the voxel cache needs so that the reference's latent one-row overrun
+ * (position == dim, opencl_kernels/utility.cl:21 with utility_ray.cl:112-117) stays in bounds */
+int64_t orc_cache_len(int32_t X, int32_t Y, int32_t Z);
+
+/* opencl_kernels/ray_marching.cl:152-199 for every work-item of the NDRange */
+int orc_render(const orc_render_params *p);
+
+/* deterministic resolve: for every pixel with hit_index >= 0 read the cache (or accum) and apply
+ * ray_marching.cl:82-99; miss pixels keep what orc_render wrote (env colour, alpha 200) */
+int orc_resolve(const orc_render_params *p);
+
+/* app/signed_distance_field.cpp:7-35 + opencl_kernels/signed_distance_field.cl
+ * layer_counts (optional, >= 130 ints) receives the atomic counter after each launch */
+int orc_sdf_build(const int16_t *volume, int32_t X, int32_t Y, int32_t Z, const orc_tf *tf,
+                  int8_t *sdf_out, int32_t *n_launches, int32_t *layer_counts);
+
+/* opencl_kernels/buffer_reset.cl:3-13 */
+void orc_buffer_reset(uint16_t *cache, int32_t X, int32_t Y, int32_t Z);
+
+/* app/common.hpp:5-12 Position3D(alpha, beta, 0, {1,0,0}) */
+void orc_camera_direction(double alpha, double beta, float out[3]);
+
+/* single-function probes for unit tests */
+uint32_t orc_hash(uint32_t seed);
+void orc_hemisphere_reflective(const float normal[3], int32_t seed, uint32_t gx, uint32_t gy,
+                               float roughness, float out[3]);
+void orc_generate_ray(const float cam_pos[3], const float cam_dir[3], int32_t x, int32_t y,
+                      int32_t x_total, int32_t y_total, float out_dir[3]);
+int orc_cut(int32_t X, int32_t Y, int32_t Z, const float origin[3], const float dir[3],
+            float out_point[3]);
+void orc_env_texel(const float dir[3], int32_t env_w, int32_t env_h, int32_t out_ij[2]);
+int orc_tf_eval(const orc_tf *tf, int32_t value, int32_t gradient, int32_t color[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
