@@ -1,0 +1,118 @@
+// clwh_internal.hpp -- structures shared by the host runtime and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/clwh.h"
+
+namespace clvr {
+
+// ---- transfer function as a kernel argument (uniform -> SGPRs / scalar cache)
+struct TfRuleDev {
+  int32_t v_lo, v_hi, g_lo, g_hi;
+  uint32_t flags;   // bit0 use_gradient, bit1 writes_color, bit2 terminal
+  uint32_t color;   // r | g<<8 | b<<16 | a<<24
+};
+struct TfDev {
+  int32_t n;
+  int32_t uses_gradient;
+  TfRuleDev rules[CLWH_TF_MAX_RULES];
+};
+
+enum : uint32_t { TF_USE_GRADIENT = 1u, TF_WRITES_COLOR = 2u, TF_TERMINAL = 4u };
+
+// ---- render pass arguments
+struct RenderArgs {
+  const int16_t *volume;   // linear x-fastest [z][y][x]
+  const int8_t *sdf;       // same layout
+  int32_t X, Y, Z;
+  const uint32_t *env;     // RGBA8 packed, row-major
+  int32_t env_w, env_h;
+  uint32_t *cache;         // voxel cache as 2 x u32 per entry
+  int64_t cache_entries;   // entries that may be indexed
+  uint32_t *frame;         // RGBA8 packed, row-major, frame_w x frame_h
+  int32_t frame_w, frame_h;
+  int32_t launch_w, launch_h;
+  int32_t tiles_x, tiles_y, tiles_per_row;  // 8x8 pixel tiles; tiles_per_row = ceil(tiles_x / world)
+  int32_t tile_rank, tile_world;
+  float cam_pos[3];
+  float cam_dir[3];
+  int32_t seed;
+  int32_t mode;            // clwh_accum_mode
+  float4 *accum;           // tile-major float4 per pixel slot (mode 1)
+  int64_t *hit_slot;       // tile-major scratch: cache entry or -1
+  int64_t *hit_index_out;  // optional, row-major over launch_w x launch_h
+  uint32_t *contrib_out;   // optional, row-major uint32[4]
+  uint32_t num_blocks;     // grid size (tile slots)
+  TfDev tf;
+};
+
+// ---- SDF build arguments
+struct SdfArgs {
+  const int16_t *volume;
+  int32_t X, Y, Z;
+  int8_t *ping;
+  int8_t *pong;
+  int32_t max_iterations;
+  int32_t iteration;
+  int32_t *counters;   // [layer] write counts
+  int32_t *done;       // [layer] early-out chain (fused build only; nullptr for the generic launch)
+  int32_t *counter_out;  // generic launch: the caller's `add_buffer`
+  TfDev tf;
+};
+
+// host-side launchers implemented in the .hip files
+hipError_t launch_render_v0(const RenderArgs &a, hipStream_t s);
+hipError_t launch_resolve(const RenderArgs &a, hipStream_t s);
+hipError_t launch_accum_resolve(const float4 *accum_all, int32_t tile_world, int32_t width, int32_t height,
+                                uint32_t *frame, int32_t frame_w, int32_t frame_h, hipStream_t s);
+hipError_t launch_sdf_base(const SdfArgs &a, hipStream_t s);
+hipError_t launch_sdf_layer(const SdfArgs &a, hipStream_t s);
+
+}  // namespace clvr
+
+// ---- opaque handle layouts (host only)
+struct clwh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // scratch
+  void *hit_scratch = nullptr;
+  size_t hit_scratch_bytes = 0;
+  int32_t *sdf_counters = nullptr;  // 2 x 160 ints (counters, done)
+  int8_t *sdf_pong = nullptr;
+  size_t sdf_pong_bytes = 0;
+  // timing
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_kernel_ms = -1.0f;
+};
+
+struct clwh_mem {
+  clwh_ctx *ctx = nullptr;
+  void *dptr = nullptr;
+  size_t bytes = 0;
+  bool owned = false;
+  bool is_image = false;
+  size_t dims[3] = {1, 1, 1};
+  int channels = 1;
+  int elem_kind = CLWH_ELEM_U8;
+  int flags = 0;
+  uint64_t version = 0;
+};
+
+enum clwh_kernel_id {
+  CLWH_K_EMPTY = 0,
+  CLWH_K_RENDER,
+  CLWH_K_SDF_BASE,
+  CLWH_K_SDF_LAYER,
+  CLWH_K_BUFFER_RESET
+};
+
+struct clwh_kernel {
+  clwh_ctx *ctx = nullptr;
+  int id = CLWH_K_EMPTY;
+  clwh_tf tf{};
+  bool has_tf = false;
+};

@@ -1,0 +1,200 @@
+/*
+ * clwh.h -- C ABI of libclwhip.so: the thin HIP shim that replaces the reference's
+ * `opencl_wrapper` (clw_*) layer for the volumetric path-tracing hot path on MI355X (gfx950).
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the reference
+ * repository).  Conventions:
+ *   - plain C: opaque handles, pointers and sizes; no exceptions, no callbacks;
+ *   - every function returns an int status (CLWH_OK == 0); clwh_strerror() names it;
+ *   - a handle is owned by whoever created it and is released explicitly; host pointers are
+ *     only borrowed for the duration of a call;
+ *   - one in-order HIP stream per context; push/pull are blocking like the reference's
+ *     CL_TRUE transfers; launches are asynchronous and stream-ordered;
+ *   - single host thread per context (the reference's ui::run loop).
+ * The fail-hard convention of the reference (print + exit(1), clw_helper.hpp:293-309) lives in
+ * the header-only C++ wrappers (include/clw_*.hpp), not in this ABI.
+ */
+#ifndef CLWH_H
+#define CLWH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct clwh_ctx clwh_ctx;       /* replaces clw_context        (opencl_wrapper/include/clw_context.hpp:5-28) */
+typedef struct clwh_mem clwh_mem;       /* replaces cl_mem of clw_vector / clw_image */
+typedef struct clwh_kernel clwh_kernel; /* replaces cl_program + cl_kernel of clw_function */
+
+enum clwh_status {
+  CLWH_OK = 0,
+  CLWH_ERR_INVALID_VALUE = 1,
+  CLWH_ERR_NO_DEVICE = 2,
+  CLWH_ERR_OUT_OF_MEMORY = 3,
+  CLWH_ERR_HIP = 4,            /* a HIP runtime call failed; clwh_last_hip_error() has the code */
+  CLWH_ERR_UNKNOWN_KERNEL = 5, /* (file, entry) is not one of the precompiled hot-path kernels */
+  CLWH_ERR_TF_UNSUPPORTED = 6, /* the prepended transfer-function source is outside the grammar */
+  CLWH_ERR_BAD_ARGS = 7,       /* wrong number / kind of kernel arguments */
+  CLWH_ERR_BAD_NDRANGE = 8,    /* global not a multiple of local, zero size, ... */
+  CLWH_ERR_SIZE_MISMATCH = 9
+};
+
+/* element kinds of an image channel: (signedness, sizeof) as clw_image picks them
+ * (opencl_wrapper/include/clw_image.hpp:68-110) */
+enum clwh_elem_kind {
+  CLWH_ELEM_S8 = 0, CLWH_ELEM_S16 = 1, CLWH_ELEM_S32 = 2,
+  CLWH_ELEM_U8 = 3, CLWH_ELEM_U16 = 4, CLWH_ELEM_U32 = 5,
+  CLWH_ELEM_F32 = 6
+};
+
+enum clwh_mem_flags { CLWH_MEM_READ_WRITE = 0, CLWH_MEM_READ_ONLY = 1 };
+
+/* ---- context: clw_context::clw_context / ~clw_context (opencl_wrapper/src/clw_context.cpp:38-83).
+ * The reference takes platform[0]/device[0]; here the HIP device ordinal is explicit. */
+int clwh_ctx_create(int device, clwh_ctx **out);
+/* same, but enqueue on a stream the caller owns (e.g. PyTorch's current stream); NULL = default */
+int clwh_ctx_create_on_stream(int device, void *hip_stream, clwh_ctx **out);
+int clwh_ctx_destroy(clwh_ctx *ctx);
+/* clFinish on the context's queue */
+int clwh_ctx_finish(clwh_ctx *ctx);
+void *clwh_ctx_stream(clwh_ctx *ctx);
+int clwh_ctx_device(clwh_ctx *ctx);
+
+/* ---- memory objects.
+ * clwh_mem_create    replaces clCreateBuffer in clw_vector's ctor (clw_vector.hpp:14-33)
+ * clwh_image_create  replaces clCreateImage in clw_image's ctor  (clw_image.hpp:18-137);
+ *                    dims of 0 count as 1; 1-D/2-D/3-D follows from the dims
+ * clwh_mem_wrap      adopts device memory the caller allocated (a torch tensor's data_ptr);
+ *                    never freed by the shim
+ * clwh_mem_push/pull replace the blocking clEnqueueWrite/Read{Buffer,Image}
+ *                    (clw_vector.hpp:73-86, clw_image.hpp:202-216); `bytes` must equal the object size
+ */
+int clwh_mem_create(clwh_ctx *ctx, size_t bytes, int flags, clwh_mem **out);
+int clwh_mem_wrap(clwh_ctx *ctx, void *device_ptr, size_t bytes, clwh_mem **out);
+int clwh_image_create(clwh_ctx *ctx, const size_t dims[3], int channels, int elem_kind, int flags,
+                      clwh_mem **out);
+int clwh_image_wrap(clwh_ctx *ctx, void *device_ptr, const size_t dims[3], int channels,
+                    int elem_kind, clwh_mem **out);
+int clwh_mem_push(clwh_ctx *ctx, clwh_mem *mem, const void *host, size_t bytes);
+int clwh_mem_pull(clwh_ctx *ctx, clwh_mem *mem, void *host, size_t bytes);
+int clwh_mem_release(clwh_mem *mem);
+void *clwh_mem_device_ptr(clwh_mem *mem);
+size_t clwh_mem_size(clwh_mem *mem);
+/* tell the shim that device code outside it rewrote the object (invalidates derived layouts) */
+int clwh_mem_mark_dirty(clwh_mem *mem);
+
+/* ---- kernels.
+ * clwh_kernel_get replaces clw_function's ctor (clw_function.hpp:74-111): instead of flattening
+ * `#clw_include_once`, prepending `prepend` and JIT-compiling, it looks (file, entry) up in the
+ * registry of precompiled HIP kernels and parses `prepend` (the generated `is_event_gen` source,
+ * app/ui.cpp:160-168) into a rule table that becomes a launch-time parameter.
+ * Known pairs: ("ray_marching.cl","render"), ("signed_distance_field.cl","create_base_image"),
+ * ("signed_distance_field.cl","create_signed_distance_field"), ("buffer_reset.cl","buffer_reset"),
+ * ("empty.cl","empty").
+ */
+int clwh_kernel_get(clwh_ctx *ctx, const char *file, const char *entry, const char *prepend,
+                    clwh_kernel **out);
+int clwh_kernel_release(clwh_kernel *k);
+
+enum clwh_arg_kind { CLWH_ARG_MEM = 0, CLWH_ARG_I32 = 1, CLWH_ARG_U32 = 2, CLWH_ARG_F32 = 3,
+                     CLWH_ARG_I64 = 4, CLWH_ARG_U64 = 5, CLWH_ARG_F64 = 6 };
+typedef struct clwh_arg {
+  int32_t kind;
+  int32_t reserved;
+  union {
+    clwh_mem *mem;
+    int32_t i32;
+    uint32_t u32;
+    float f32;
+    int64_t i64;
+    uint64_t u64;
+    double f64;
+  } v;
+} clwh_arg;
+
+/* clwh_launch replaces clw_function::execute (clw_function.hpp:217-244): zeros in global/local
+ * count as 1; global must be a multiple of local (the reference asserts it); the argument list is
+ * the reference kernel's own, in order (clSetKernelArg by position, clw_function.hpp:152-167). */
+int clwh_launch(clwh_kernel *k, const size_t global[3], const size_t local[3], const clwh_arg *args,
+                int nargs);
+
+/* ---- hot-path entry points beyond the generic launch (used by the C++ host mirror and bench).
+ *
+ * clwh_render: one `render` pass = one sample per pixel (app/renderer.cpp:145-148 +
+ * opencl_kernels/ray_marching.cl:152-199), with the options the MI355X design adds.
+ */
+enum clwh_accum_mode {
+  CLWH_ACCUM_VOXEL_CACHE = 0, /* reference-exact world-space cache (utility.cl:20-54) */
+  CLWH_ACCUM_IMAGE_SPACE = 1  /* per-pixel float4 {r,g,b,count}, no token cap (multi-GPU tiles) */
+};
+typedef struct clwh_render_desc {
+  clwh_mem *frame;          /* RGBA8 2-D image; its dims are what get_image_width/height(frame) return */
+  clwh_mem *volume;         /* S16 3-D image */
+  clwh_mem *sdf;            /* S8 3-D image */
+  clwh_mem *env;            /* RGBA8 2-D image */
+  clwh_mem *buffer_volume;  /* voxel cache, clwh_cache_len() ushorts (mode 0) */
+  float cam_pos[3];
+  float cam_dir[3];
+  int32_t seed;
+  uint32_t width, height;   /* NDRange global size (multiples of 8) */
+  int32_t accum_mode;
+  clwh_mem *accum;          /* mode 1: float4 per pixel, tile-major (see clwh_accum_len) */
+  int32_t tile_rank, tile_world; /* image-tile partition: 8x8 tiles, owner = (tx + ty) % world */
+  int32_t write_frame;      /* 1: resolve the frame (deterministic, after all adds of the pass) */
+  clwh_mem *hit_index;      /* optional int64 per pixel, row-major: cache entry or -1 (parity tests) */
+  clwh_mem *contrib;        /* optional uint32[4] per pixel, row-major: r,g,b,granted (parity tests) */
+} clwh_render_desc;
+int clwh_render(clwh_kernel *render_kernel, const clwh_render_desc *desc);
+
+/* number of ushorts of a voxel cache for an X*Y*Z volume (the reference allocates X*Y*Z*4,
+ * app/renderer.cpp:29-30, and can index one row past it, utility.cl:21 with utility_ray.cl:112-117;
+ * the shim's kernels require the padded length) */
+int64_t clwh_cache_len(uint32_t X, uint32_t Y, uint32_t Z);
+/* number of float4 of a rank's tile-major accumulation buffer */
+int64_t clwh_accum_len(uint32_t width, uint32_t height, int32_t tile_world);
+/* scatter one rank's tile-major accumulation tiles into a row-major float4 frame and resolve the
+ * RGBA8 frame from it (ray_marching.cl:82-99 applied per pixel); used after the RCCL gather */
+int clwh_accum_resolve(clwh_ctx *ctx, clwh_mem *accum_all_ranks, int32_t tile_world, uint32_t width,
+                       uint32_t height, clwh_mem *frame_rgba8);
+
+/* clwh_sdf_build replaces the host loop of signed_distance_field::signed_distance_field
+ * (app/signed_distance_field.cpp:7-35): base image + all propagation layers, no host round trip
+ * per layer.  `sdf` is an S8 3-D image of the volume's dims.  n_launches (optional) receives the
+ * number of create_signed_distance_field layers the reference's loop would have run. */
+int clwh_sdf_build(clwh_ctx *ctx, clwh_mem *volume, const char *tf_source, clwh_mem *sdf,
+                   int32_t *n_launches);
+
+/* buffer_reset.cl:3-13 / app/renderer.cpp:32-35 */
+int clwh_buffer_reset(clwh_ctx *ctx, clwh_mem *buffer_volume);
+
+/* ---- transfer function: the parsed form of the generated `is_event_gen` source */
+#define CLWH_TF_MAX_RULES 16
+typedef struct clwh_tf_rule {
+  int32_t v_lo, v_hi;   /* value    in [v_lo, v_hi] */
+  int32_t g_lo, g_hi;   /* gradient in [g_lo, g_hi] when use_gradient */
+  int32_t use_gradient;
+  int32_t writes_color;
+  int32_t terminal;
+  int32_t color[4];
+} clwh_tf_rule;
+typedef struct clwh_tf {
+  int32_t n;
+  clwh_tf_rule rules[CLWH_TF_MAX_RULES];
+} clwh_tf;
+int clwh_tf_parse(const char *source, clwh_tf *out);
+
+/* ---- diagnostics */
+const char *clwh_strerror(int status);
+int clwh_last_hip_error(void);
+const char *clwh_version(void);
+/* per-context timing of the most recent clwh_render, measured with HIP events on the context's
+ * stream around the dominant kernel (ms; < 0 when timing is off) */
+int clwh_ctx_set_timing(clwh_ctx *ctx, int enabled);
+float clwh_ctx_last_kernel_ms(clwh_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLWH_H */

@@ -117,7 +117,7 @@ def lib():
 # (csrc/tf_parse.cpp); tests compare the two.
 
 _NUM = r"[-+]?(?:\d+\.?\d*(?:[eE][-+]?\d+)?|\.\d+(?:[eE][-+]?\d+)?|inf|nan)"
-_CMP = re.compile(r"\s*(value|gradient)\s*(>=|<=|>|<|==)\s*(" + _NUM + r")\s*")
+_CMP = re.compile(r"\s*(value|gradient)\s*(>=|<=|>|<|==)\s*(" + _NUM + r")[fF]?\s*")
 _SHORT_MIN, _SHORT_MAX = -32768, 32767
 
 
@@ -143,6 +143,9 @@ def _apply_cmp(bounds, var, op, lit):
 def _parse_cond(cond: str):
     bounds = {"value": (_SHORT_MIN, _SHORT_MAX), "gradient": (_SHORT_MIN, _SHORT_MAX)}
     uses_g = False
+    cond = cond.strip()
+    while cond.startswith("(") and cond.endswith(")") and cond.count("(") == 1:
+        cond = cond[1:-1].strip()
     for term in cond.split("&&"):
         t = term.strip()
         while t.startswith("(") and t.endswith(")"):

@@ -1,0 +1,52 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (test infrastructure).  Built on demand with gcc."""
+    from oracle import orc_ffi
+
+    orc_ffi.build()
+    orc_ffi.lib()
+    return orc_ffi
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def sdf_golden(golden_dir):
+    """The reference's own SDF test data: tests/sdf/testdata.nrrd + tests/sdf/values.x (copied verbatim)."""
+    import numpy as np
+
+    from cl_volume_renderer_amd import scene
+
+    vol = scene.read_nrrd(os.path.join(golden_dir, "sdf_testdata.nrrd"))
+    vals = np.array(
+        [int(line.strip().rstrip(",")) for line in open(os.path.join(golden_dir, "sdf_values.x")) if line.strip()],
+        dtype=np.int32,
+    )
+    return vol, vals
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx():
+    """A clwh context on cuda:0 -- fails loudly if the HIP library or the GPU is missing."""
+    from cl_volume_renderer_amd import ffi
+
+    ctx = ffi.Context(0)
+    yield ctx
+    ctx.destroy()

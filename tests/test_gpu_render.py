@@ -1,0 +1,169 @@
+"""-m gpu: the render pass on the MI355X through the C ABI against the CPU oracle.
+
+Parity targets: hit voxel per pixel, per-sample contribution, the voxel cache after K
+passes (below the 256-token cap), the deterministic resolve of the frame, the image-space
+accumulation -- all bit-exact; the reference's raw racy frame is not a target."""
+import numpy as np
+import pytest
+
+from cl_volume_renderer_amd import ffi, scene
+from tests.gpu_util import GpuScene, look_at_centre, small_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _compare_passes(orc, ctx, vol, sdf, env, tf_source, frame_wh, pos, d, seeds, launch_wh=None):
+    g = GpuScene(ctx, vol, sdf, env, tf_source, frame_wh, launch_wh)
+    o = orc.Scene(vol, sdf, env, orc.parse_tf(tf_source), frame_wh, launch_wh)
+    for s in seeds:
+        g.render(pos, d, s)
+        o.render(pos, d, s)
+        assert np.array_equal(g.hit_index.pull(), o.hit_index), "primary hit voxel per pixel"
+        assert np.array_equal(g.contrib.pull(), o.contrib), "per-sample contribution"
+    assert o.cache.reshape(-1, 4)[:, 3].max() < 256, "test must stay below the token cap"
+    assert np.array_equal(g.cache.pull(), o.cache), "voxel cache"
+    o.resolve(pos, d)
+    assert np.array_equal(g.frame.pull(), o.frame), "resolved frame"
+    stats = dict(hits=int((o.hit_index >= 0).sum()), touched=int((o.cache.reshape(-1, 4)[:, 3] > 0).sum()))
+    g.release()
+    return stats
+
+
+def test_voxel_cache_parity_phantom64(gpu_ctx, orc):
+    vol, sdf, env, tf = small_scene(orc, 64)
+    pos, d = look_at_centre(vol, [-25, 50, -25])
+    st = _compare_passes(orc, gpu_ctx, vol, sdf, env, tf, (256, 256), pos, d, scene.glibc_rand(6))
+    assert st["hits"] > 10000 and st["touched"] > 1000
+
+
+def test_voxel_cache_parity_default_camera_128(gpu_ctx, orc):
+    vol, sdf, env, tf = small_scene(orc, 128, env_wh=(1024, 512))
+    pos, d = scene.default_camera(128)
+    st = _compare_passes(orc, gpu_ctx, vol, sdf, env, tf, (512, 288), pos, d, scene.glibc_rand(8)[4:])
+    assert st["hits"] > 10000
+
+
+def test_gradient_tf_parity(gpu_ctx, orc):
+    """the 7-texel step: TF reads `gradient`"""
+    vol, sdf, env, tf = small_scene(orc, 48, tf_source=scene.tf_gradient_source())
+    pos, d = look_at_centre(vol, [-20, 40, -30])
+    st = _compare_passes(orc, gpu_ctx, vol, sdf, env, tf, (128, 128), pos, d, scene.glibc_rand(3))
+    assert st["hits"] > 1000
+
+
+def test_two_material_tf_with_partial_roughness(gpu_ctx, orc):
+    tf = scene.tf_rect_source([(500.0, 1200.0, 0.0, 4000.0, (1.0, 0.7, 0.4, 0.35)),
+                               (20.0, 60.0, 0.0, 4000.0, (0.3, 0.9, 0.5, 0.9))])
+    vol, sdf, env, tf = small_scene(orc, 48, tf_source=tf)
+    pos, d = look_at_centre(vol, [-20, 30, -30])
+    _compare_passes(orc, gpu_ctx, vol, sdf, env, tf, (128, 128), pos, d, scene.glibc_rand(3))
+
+
+def test_reference_sdf_test_volume(gpu_ctx, orc, sdf_golden):
+    """the only real data the reference ships: tests/sdf/testdata.nrrd with its test TF"""
+    vol, gold = sdf_golden
+    sdf = gold.reshape(vol.shape).astype(np.int8)
+    env = scene.env_map(128, 64)
+    pos, d = look_at_centre(vol, [-30, 60, -40])
+    # `return (value > 800);` never assigns *color -> zero energy; geometry and token counts still exercise
+    _compare_passes(orc, gpu_ctx, vol, sdf, env, scene.TF_TEST_VALUE_GT_800, (128, 128), pos, d, [7, 8])
+    tf = scene.tf_rect_source([(800.5, 3000.0, 0.0, 4000.0, (0.9, 0.8, 0.7, 1.0))])
+    sdf2, _, _ = orc.sdf_build(vol, orc.parse_tf(tf))
+    st = _compare_passes(orc, gpu_ctx, vol, sdf2, env, tf, (128, 128), pos, d, [7, 8, 9])
+    assert st["hits"] > 500
+
+
+def test_non_cubic_volume_and_wide_frame(gpu_ctx, orc):
+    vol, sdf, env, tf = small_scene(orc, 64, dims=(72, 40, 56))
+    pos, d = look_at_centre(vol, [-30, 55, -20])
+    _compare_passes(orc, gpu_ctx, vol, sdf, env, tf, (320, 64), pos, d, [11, 12])
+
+
+def test_camera_inside_volume_and_all_miss(gpu_ctx, orc):
+    vol, sdf, env, tf = small_scene(orc, 48)
+    inside = np.array([24.0, 24.0, 24.0], np.float32)
+    _compare_passes(orc, gpu_ctx, vol, sdf, env, tf, (64, 64), inside, scene.camera_direction(0.3, 0.2), [5, 6])
+    pos = np.array([-100, 200, -100], np.float32)
+    away = np.array([-0.6, 0.5, -0.6], np.float32)
+    away /= np.linalg.norm(away)
+    st = _compare_passes(orc, gpu_ctx, vol, sdf, env, tf, (64, 64), pos, away.astype(np.float32), [5])
+    assert st["hits"] == 0
+
+
+def test_frame_image_larger_than_launch(gpu_ctx, orc):
+    """the reference allocates a 2048x1024 frame whatever the launch size (renderer.cpp:11,145);
+    generate_ray uses the IMAGE dims (ray_marching.cl:162)."""
+    vol, sdf, env, tf = small_scene(orc, 32)
+    pos, d = look_at_centre(vol, [-15, 30, -15])
+    _compare_passes(orc, gpu_ctx, vol, sdf, env, tf, (128, 96), pos, d, [3], launch_wh=(64, 48))
+
+
+def test_generic_launch_is_the_reference_call(gpu_ctx, orc):
+    """render_func.execute({w,h},{8,8}, frame, volume, sdf, env, buffer_volume, pos.xyz, dir.xyz, seed)
+    (app/renderer.cpp:145-148) through clwh_launch, with the reference's UNPADDED cache allocation."""
+    vol, sdf, env, tf = small_scene(orc, 48)
+    pos, d = look_at_centre(vol, [-20, 40, -20])
+    g = GpuScene(gpu_ctx, vol, sdf, env, tf, (96, 96), padded_cache=False)
+    o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (96, 96))
+    for s in scene.glibc_rand(3):
+        g.kernel.launch([96, 96], [8, 8], g.frame, g.volume, g.sdf, g.env, g.cache,
+                        float(pos[0]), float(pos[1]), float(pos[2]), float(d[0]), float(d[1]), float(d[2]), int(s))
+        o.render(pos, d, s)
+    n = 48 * 48 * 48 * 4
+    assert np.array_equal(g.cache.pull(), o.cache[:n]) and not o.cache[n:].any()
+    o.resolve(pos, d)
+    assert np.array_equal(g.frame.pull(), o.frame)
+    with pytest.raises(ffi.ClwhError) as e:  # 100 is not a multiple of the 8x8 work-group
+        g.kernel.launch([100, 96], [8, 8], g.frame, g.volume, g.sdf, g.env, g.cache,
+                        0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1)
+    assert e.value.status == 8
+    g.release()
+
+
+def test_token_cap_is_reached_exactly(gpu_ctx, orc):
+    """utility.cl:20-31: no voxel ever holds more than 256 samples; lanes never carry."""
+    vol, sdf, env, tf = small_scene(orc, 32)
+    pos, d = look_at_centre(vol, [-12, 25, -12])
+    g = GpuScene(gpu_ctx, vol, sdf, env, tf, (256, 256))
+    for s in scene.glibc_rand(40):
+        g.render(pos, d, s, debug=False)
+    c = g.cache.pull().reshape(-1, 4)
+    assert c[:, 3].max() == 256 and (c[:, 3] == 256).sum() > 100
+    assert c[:, :3].max() <= 256 * 255
+    g.release()
+
+
+def test_image_space_mode_and_tile_partition(gpu_ctx, orc):
+    """float4 accumulation per pixel (north_star's multi-GPU mode): exact, and the union of the
+    tile-partitioned ranks equals the single-rank result."""
+    vol, sdf, env, tf = small_scene(orc, 48)
+    pos, d = look_at_centre(vol, [-20, 40, -20])
+    w, h = 192, 128
+    seeds = scene.glibc_rand(3)
+    o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (w, h), mode=orc.MODE_IMAGE_SPACE)
+    one = GpuScene(gpu_ctx, vol, sdf, env, tf, (w, h), world=1)
+    for s in seeds:
+        o.render(pos, d, s)
+        one.render(pos, d, s, mode=ffi.ACCUM_IMAGE_SPACE)
+    o.resolve(pos, d)
+    got = one.accum_row_major(0)
+    hit = o.hit_index.reshape(h, w) >= 0
+    assert np.array_equal(got[hit], o.accum[hit])
+    assert np.all(got[~hit][:, 3] == 0)
+    assert np.array_equal(one.frame.pull(), o.frame)
+
+    for world in (2, 3):
+        many = GpuScene(gpu_ctx, vol, sdf, env, tf, (w, h), world=world)
+        for r in range(world):
+            for s in seeds:
+                many.render(pos, d, s, mode=ffi.ACCUM_IMAGE_SPACE, rank=r, write_frame=False)
+        merged = sum(many.accum_row_major(r) for r in range(world))
+        assert np.array_equal(merged, got)
+        # what the RCCL all-gather produces: the ranks' buffers back to back -> one resolve
+        allr = np.concatenate([many.accum[r].pull(np.float32) for r in range(world)])
+        buf = gpu_ctx.buffer_from(allr)
+        gpu_ctx.accum_resolve(buf, world, w, h, many.frame)
+        assert np.array_equal(many.frame.pull(), o.frame)
+        buf.release()
+        many.release()
+    one.release()

@@ -1,0 +1,93 @@
+"""-m gpu: SDF builder on the MI355X through the C ABI, against the reference's golden vector and the oracle."""
+import numpy as np
+import pytest
+
+from cl_volume_renderer_amd import ffi, scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _upload(ctx, vol):
+    Z, Y, X = vol.shape
+    v = ctx.image_from(vol.astype(np.int16))
+    s = ctx.image([X, Y, Z], 1, np.int8, (Z, Y, X))
+    return v, s
+
+
+def test_fused_build_matches_reference_golden_vector(gpu_ctx, sdf_golden):
+    """reference tests/sdf/sdf_test.cpp:6-33 re-run on the HIP path: exact."""
+    vol, gold = sdf_golden
+    v, s = _upload(gpu_ctx, vol)
+    n = gpu_ctx.sdf_build(v, scene.TF_TEST_VALUE_GT_800, s)
+    out = s.pull()
+    assert np.array_equal(out.reshape(-1).astype(np.int32), gold)
+    assert n == 13
+    v.release(); s.release()
+
+
+def test_reference_host_loop_over_the_generic_launch(gpu_ctx, sdf_golden):
+    """app/signed_distance_field.cpp:7-35 re-enacted call by call over clwh_kernel_get / clwh_launch,
+    i.e. what the reference's unmodified host code would do through the clw_* wrappers."""
+    vol, gold = sdf_golden
+    Z, Y, X = vol.shape
+    ctx = gpu_ctx
+    v = ctx.image_from(vol.astype(np.int16))
+    sdf = ctx.image([X, Y, Z], 1, np.int8, (Z, Y, X)); sdf.push(np.zeros((Z, Y, X), np.int8))
+    pong = ctx.image([X, Y, Z], 1, np.int8, (Z, Y, X))
+    code = scene.TF_TEST_VALUE_GT_800
+    max_it = min(max(X, Y, Z) // 2, 127)
+    ev = lambda g, l: (g + l - 1) // l * l  # noqa: E731  evenness(), app/common.hpp:59-66
+    gsz = [ev(X, 8), ev(Y, 8), ev(Z, 8)]
+    ctx.kernel("signed_distance_field.cl", "create_base_image", code).launch(gsz, [4, 4, 4], v, sdf, pong, np.uint32(max_it))
+    layer = ctx.kernel("signed_distance_field.cl", "create_signed_distance_field", code)
+    counter = ctx.buffer(4, np.int32)
+    ping_, pong_ = sdf, pong
+    launches = 0
+    for i in range(1, max_it + (max_it % 2) + 1 + 1):
+        counter.push(np.zeros(1, np.int32))
+        layer.launch(gsz, [4, 4, 4], ping_, pong_, np.uint32(i), counter, np.uint32(max_it))
+        ping_, pong_ = pong_, ping_
+        launches += 1
+        if counter.pull()[0] == 0 and i % 2 == 1:
+            break
+    assert launches == 13
+    assert np.array_equal(sdf.pull().reshape(-1).astype(np.int32), gold)
+    for m in (v, sdf, pong, counter):
+        m.release()
+
+
+@pytest.mark.parametrize("dims,tf", [
+    ((64, 64, 64), "default"), ((64, 64, 64), "gradient"), ((70, 33, 45), "default"), ((40, 96, 24), "gradient"),
+])
+def test_fused_build_matches_oracle(gpu_ctx, orc, dims, tf):
+    src = scene.tf_default_source() if tf == "default" else scene.tf_gradient_source()
+    vol = scene.phantom(max(dims), dims=dims)
+    want, n_want, _ = orc.sdf_build(vol, orc.parse_tf(src))
+    v, s = _upload(gpu_ctx, vol)
+    n = gpu_ctx.sdf_build(v, src, s)
+    got = s.pull()
+    assert np.array_equal(got, want)
+    assert n == n_want
+    v.release(); s.release()
+
+
+def test_degenerate_volumes(gpu_ctx, orc):
+    """all-event and no-event volumes: nothing to propagate, the loop stops at the first odd layer."""
+    for fill in (-1000, 900):
+        vol = np.full((16, 16, 16), fill, np.int16)
+        want, n_want, _ = orc.sdf_build(vol, orc.parse_tf(scene.tf_default_source()))
+        v, s = _upload(gpu_ctx, vol)
+        n = gpu_ctx.sdf_build(v, scene.tf_default_source(), s)
+        assert np.array_equal(s.pull(), want) and n == n_want == 1
+        v.release(); s.release()
+
+
+def test_unknown_kernel_and_bad_ndrange_are_reported(gpu_ctx):
+    with pytest.raises(ffi.ClwhError) as e:
+        gpu_ctx.kernel("histogram.cl", "tf_sort_values")
+    assert e.value.status == 5
+    k = gpu_ctx.kernel("empty.cl", "empty")
+    with pytest.raises(ffi.ClwhError) as e:
+        k.launch([10, 8, 1], [4, 4, 1])  # clw_function.hpp:235 asserts global % local == 0
+    assert e.value.status == 8
+    k.release()
