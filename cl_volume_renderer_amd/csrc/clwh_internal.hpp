@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/clwh.h"
 
 namespace clvr {
@@ -83,10 +85,11 @@ struct clwh_ctx {
   int32_t *sdf_counters = nullptr;  // 2 x 160 ints (counters, done)
   int8_t *sdf_pong = nullptr;
   size_t sdf_pong_bytes = 0;
-  // timing
+  // timing: one HIP event pair per clwh_render, recorded on the context's stream around the
+  // dominant kernel and read back (without a sync per pass) by clwh_ctx_timing_read
   bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  float last_kernel_ms = -1.0f;
+  std::vector<hipEvent_t> ev_begin, ev_end;
+  size_t ev_used = 0;
 };
 
 struct clwh_mem {

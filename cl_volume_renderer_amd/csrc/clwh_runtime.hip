@@ -97,8 +97,8 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
   if (ctx->hit_scratch) (void)hipFree(ctx->hit_scratch);
   if (ctx->sdf_counters) (void)hipFree(ctx->sdf_counters);
   if (ctx->sdf_pong) (void)hipFree(ctx->sdf_pong);
-  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  for (hipEvent_t e : ctx->ev_begin) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->ev_end) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return CLWH_OK;
@@ -115,23 +115,39 @@ int clwh_ctx_device(clwh_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 int clwh_ctx_set_timing(clwh_ctx *ctx, int enabled) {
   if (!ctx) return CLWH_ERR_INVALID_VALUE;
-  if (enabled && !ctx->ev0) {
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipEventCreate(&ctx->ev0));
-    HIP_TRY(hipEventCreate(&ctx->ev1));
-  }
   ctx->timing = enabled != 0;
-  ctx->last_kernel_ms = -1.0f;
+  ctx->ev_used = 0;
   return CLWH_OK;
 }
 
-float clwh_ctx_last_kernel_ms(clwh_ctx *ctx) {
-  if (!ctx || !ctx->timing || !ctx->ev1) return -1.0f;
-  if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0f;
-  float ms = -1.0f;
-  if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0f;
-  ctx->last_kernel_ms = ms;
-  return ms;
+int clwh_ctx_timing_read(clwh_ctx *ctx, float *total_ms, int32_t *launches) {
+  if (!ctx || !total_ms || !launches) return CLWH_ERR_INVALID_VALUE;
+  *total_ms = 0.0f;
+  *launches = 0;
+  HIP_TRY(hipSetDevice(ctx->device));
+  for (size_t i = 0; i < ctx->ev_used; ++i) {
+    HIP_TRY(hipEventSynchronize(ctx->ev_end[i]));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_begin[i], ctx->ev_end[i]));
+    *total_ms += ms;
+    *launches += 1;
+  }
+  ctx->ev_used = 0;
+  return CLWH_OK;
+}
+
+static int timing_slot(clwh_ctx *ctx, hipEvent_t *b, hipEvent_t *e) {
+  if (ctx->ev_used == ctx->ev_begin.size()) {
+    hipEvent_t x, y;
+    HIP_TRY(hipEventCreate(&x));
+    HIP_TRY(hipEventCreate(&y));
+    ctx->ev_begin.push_back(x);
+    ctx->ev_end.push_back(y);
+  }
+  *b = ctx->ev_begin[ctx->ev_used];
+  *e = ctx->ev_end[ctx->ev_used];
+  ctx->ev_used++;
+  return CLWH_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -404,9 +420,14 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   if (rc != CLWH_OK) return rc;
   a.hit_slot = (int64_t *)ctx->hit_scratch;
 
-  if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  hipEvent_t ev_b = nullptr, ev_e = nullptr;
+  if (ctx->timing) {
+    rc = timing_slot(ctx, &ev_b, &ev_e);
+    if (rc != CLWH_OK) return rc;
+    HIP_TRY(hipEventRecord(ev_b, ctx->stream));
+  }
   HIP_TRY(launch_render_v0(a, ctx->stream));
-  if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  if (ctx->timing) HIP_TRY(hipEventRecord(ev_e, ctx->stream));
   if (d->write_frame && a.frame) HIP_TRY(launch_resolve(a, ctx->stream));
   if (d->frame) d->frame->version++;
   return CLWH_OK;

@@ -101,7 +101,7 @@ _PROTOTYPES = [
     ("clwh_last_hip_error", C.c_int, []),
     ("clwh_version", C.c_char_p, []),
     ("clwh_ctx_set_timing", C.c_int, [C.c_void_p, C.c_int]),
-    ("clwh_ctx_last_kernel_ms", C.c_float, [C.c_void_p]),
+    ("clwh_ctx_timing_read", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
 ]
 EXPORTED_SYMBOLS = [p[0] for p in _PROTOTYPES]
 
@@ -285,8 +285,11 @@ class Context:
     def set_timing(self, enabled=True):
         _check(lib().clwh_ctx_set_timing(self.h, 1 if enabled else 0), "clwh_ctx_set_timing")
 
-    def last_kernel_ms(self) -> float:
-        return float(lib().clwh_ctx_last_kernel_ms(self.h))
+    def timing_read(self):
+        """(total ms, launches) of the dominant render kernel since the last read (HIP events)."""
+        ms, n = C.c_float(0), C.c_int32(0)
+        _check(lib().clwh_ctx_timing_read(self.h, C.byref(ms), C.byref(n)), "clwh_ctx_timing_read")
+        return float(ms.value), int(n.value)
 
     @property
     def stream(self) -> int:

@@ -189,10 +189,11 @@ int clwh_tf_parse(const char *source, clwh_tf *out);
 const char *clwh_strerror(int status);
 int clwh_last_hip_error(void);
 const char *clwh_version(void);
-/* per-context timing of the most recent clwh_render, measured with HIP events on the context's
- * stream around the dominant kernel (ms; < 0 when timing is off) */
+/* per-context timing of the dominant kernel of clwh_render: when enabled, every clwh_render records
+ * a HIP event pair on the context's stream around that kernel (no host sync per pass);
+ * clwh_ctx_timing_read waits for them, returns the summed duration and launch count, and resets. */
 int clwh_ctx_set_timing(clwh_ctx *ctx, int enabled);
-float clwh_ctx_last_kernel_ms(clwh_ctx *ctx);
+int clwh_ctx_timing_read(clwh_ctx *ctx, float *total_ms, int32_t *launches);
 
 #ifdef __cplusplus
 }

@@ -453,6 +453,7 @@ static u4 compute_light(ctx_t *c, ray_t surface_ray, int32_t random_seed, int64_
       atomic_buffer_volume_add4(c, entry, buffer_value);
     } else {
       float *a = p->accum + ((int64_t)c->gy * p->launch_w + c->gx) * 4;
+      c->c[ORC_N_ADD]++;
       a[0] += (float)contribution->x;
       a[1] += (float)contribution->y;
       a[2] += (float)contribution->z;
