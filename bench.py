@@ -37,6 +37,19 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def host_threads():
+    """Threads for the CPU baseline: the cores this process may really use (affinity, cgroup quota),
+    capped at the 16-core share a one-GPU box grants."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("BENCH_CPU_THREADS", "16"))))
+
+
 def image_space_bytes(c, samples):
     """Algorithmic bytes of the image-space pass (DESIGN.md 'Measurement'): SURVEY 8d's formula with
     the accumulation done per pixel: no token, float4 read-modify-write (32 B) per granted sample,
@@ -182,7 +195,7 @@ def main():
     if rank == 0:
         from oracle import orc_ffi
 
-        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = host_threads()
         sdf_host = d_sdf.pull()
         osc = orc_ffi.Scene(vol, sdf_host, env, orc_ffi.parse_tf(tf_source), (W, H), mode=orc_ffi.MODE_IMAGE_SPACE,
                             tile_rank=0, tile_world=world, threads=threads)
