@@ -47,6 +47,18 @@ struct RenderArgs {
   int64_t *hit_index_out;  // optional, row-major over launch_w x launch_h
   uint32_t *contrib_out;   // optional, row-major uint32[4]
   uint32_t num_blocks;     // grid size (tile slots)
+  const uint32_t *packed;  // bricked {value, sdf, class} records (packed_volume.hpp); nullptr = linear path
+  int32_t NBX, NBY;
+  TfDev tf;
+};
+
+// ---- repack arguments (volume + sdf + TF -> packed records)
+struct RepackArgs {
+  const int16_t *volume;
+  const int8_t *sdf;
+  int32_t X, Y, Z;
+  int32_t NBX, NBY, NBZ;
+  uint32_t *packed;
   TfDev tf;
 };
 
@@ -66,6 +78,7 @@ struct SdfArgs {
 
 // host-side launchers implemented in the .hip files
 hipError_t launch_render_v0(const RenderArgs &a, hipStream_t s);
+hipError_t launch_repack(const RepackArgs &a, hipStream_t s);
 hipError_t launch_resolve(const RenderArgs &a, hipStream_t s);
 hipError_t launch_accum_resolve(const float4 *accum_all, int32_t tile_world, int32_t width, int32_t height,
                                 uint32_t *frame, int32_t frame_w, int32_t frame_h, hipStream_t s);
@@ -85,6 +98,14 @@ struct clwh_ctx {
   int32_t *sdf_counters = nullptr;  // 2 x 160 ints (counters, done)
   int8_t *sdf_pong = nullptr;
   size_t sdf_pong_bytes = 0;
+  // derived packed volume (single entry, keyed by the source objects' identity + version and the TF)
+  uint32_t *packed = nullptr;
+  size_t packed_bytes = 0;
+  const void *packed_vol = nullptr, *packed_sdf = nullptr;
+  uint64_t packed_vol_ver = 0, packed_sdf_ver = 0;
+  clvr::TfDev packed_tf{};
+  bool packed_valid = false;
+  bool use_linear_path = false;  // CLWH_RENDER_PATH=linear: A/B switch for measurements
   // timing: one HIP event pair per clwh_render, recorded on the context's stream around the
   // dominant kernel and read back (without a sync per pass) by clwh_ctx_timing_read
   bool timing = false;

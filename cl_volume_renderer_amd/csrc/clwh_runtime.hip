@@ -6,6 +6,7 @@
 // transfer-function source parsed into a launch-time table instead of being JIT-compiled.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -70,6 +71,8 @@ int clwh_ctx_create_on_stream(int device, void *hip_stream, clwh_ctx **out) {
   c->device = device;
   c->stream = (hipStream_t)hip_stream;
   c->own_stream = false;
+  const char *path = std::getenv("CLWH_RENDER_PATH");
+  c->use_linear_path = path && !std::strcmp(path, "linear");
   *out = c;
   return CLWH_OK;
 }
@@ -97,6 +100,7 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
   if (ctx->hit_scratch) (void)hipFree(ctx->hit_scratch);
   if (ctx->sdf_counters) (void)hipFree(ctx->sdf_counters);
   if (ctx->sdf_pong) (void)hipFree(ctx->sdf_pong);
+  if (ctx->packed) (void)hipFree(ctx->packed);
   for (hipEvent_t e : ctx->ev_begin) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_end) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -345,6 +349,44 @@ static int ensure_scratch(clwh_ctx *ctx, size_t bytes) {
   return CLWH_OK;
 }
 
+// (re)build the packed {value, sdf, class} records when the volume, the SDF or the TF changed
+static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *sdf, const TfDev &tf) {
+  const int X = (int)volume->dims[0], Y = (int)volume->dims[1], Z = (int)volume->dims[2];
+  const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 7) / 8;
+  const size_t bytes = (size_t)NBX * NBY * NBZ * 512u * sizeof(uint32_t);
+  if (ctx->packed_valid && ctx->packed_bytes == bytes && ctx->packed_vol == volume->dptr &&
+      ctx->packed_sdf == sdf->dptr && ctx->packed_vol_ver == volume->version &&
+      ctx->packed_sdf_ver == sdf->version && !std::memcmp(&ctx->packed_tf, &tf, sizeof tf))
+    return CLWH_OK;
+  ctx->packed_valid = false;
+  if (ctx->packed_bytes != bytes) {
+    if (ctx->packed) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      HIP_TRY(hipFree(ctx->packed));
+      ctx->packed = nullptr;
+      ctx->packed_bytes = 0;
+    }
+    HIP_TRY(hipMalloc((void **)&ctx->packed, bytes));
+    ctx->packed_bytes = bytes;
+  }
+  RepackArgs r;
+  std::memset(&r, 0, sizeof r);
+  r.volume = (const int16_t *)volume->dptr;
+  r.sdf = (const int8_t *)sdf->dptr;
+  r.X = X; r.Y = Y; r.Z = Z;
+  r.NBX = NBX; r.NBY = NBY; r.NBZ = NBZ;
+  r.packed = ctx->packed;
+  r.tf = tf;
+  HIP_TRY(launch_repack(r, ctx->stream));
+  ctx->packed_vol = volume->dptr;
+  ctx->packed_sdf = sdf->dptr;
+  ctx->packed_vol_ver = volume->version;
+  ctx->packed_sdf_ver = sdf->version;
+  ctx->packed_tf = tf;
+  ctx->packed_valid = true;
+  return CLWH_OK;
+}
+
 int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   if (!k || !d || k->id != CLWH_K_RENDER || !k->has_tf) return CLWH_ERR_INVALID_VALUE;
   clwh_ctx *ctx = k->ctx;
@@ -419,6 +461,13 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   int rc = ensure_scratch(ctx, (size_t)a.num_blocks * 64u * sizeof(int64_t));
   if (rc != CLWH_OK) return rc;
   a.hit_slot = (int64_t *)ctx->hit_scratch;
+  if (!ctx->use_linear_path) {
+    rc = ensure_packed(ctx, d->volume, d->sdf, a.tf);
+    if (rc != CLWH_OK) return rc;
+    a.packed = ctx->packed;
+    a.NBX = (a.X + 7) / 8;
+    a.NBY = (a.Y + 7) / 8;
+  }
 
   hipEvent_t ev_b = nullptr, ev_e = nullptr;
   if (ctx->timing) {

@@ -1,0 +1,54 @@
+// packed_volume.hpp -- the MI355X-native resident form of (volume, SDF, transfer function).
+//
+// The reference samples two images per march step: the SDF at trunc(origin) before the step and the
+// volume at floor(origin) after it (utility_ray.cl:148-154, :126-138).  Inside the volume both
+// addresses of consecutive steps coincide, so the shim keeps ONE 4-byte record per voxel
+//     bits  0..15  value   (int16, the volume texel)
+//     bits 16..23  sdf     (int8, the distance-field texel)
+//     bits 24..31  class   (1 + index of the first transfer-function rule the value satisfies, 0 = no
+//                           event; only when no rule reads `gradient`)
+// and one gather per step returns the classification of the new position AND the step length of the
+// next step.  Records are stored in 8x8x8 bricks made of eight 4x4x4 sub-bricks (256 B each, x
+// fastest inside), so the 64 rays of an 8x8 pixel tile, which walk a tube a few voxels wide, share
+// a handful of 128-B lines instead of one line per (y,z) row as in the caller's x-fastest layout.
+// The packed volume is derived data: built by k_repack at the first render after the volume, the
+// SDF or the transfer function changed.
+#pragma once
+
+#include "device_math.hpp"
+
+namespace clvr {
+
+struct VolumePacked {
+  const uint32_t *__restrict__ rec;
+  int X, Y, Z;
+  int NBX, NBY;  // bricks per row / per slice
+
+  __host__ __device__ static inline size_t record_index(int x, int y, int z, int nbx, int nby) {
+    const size_t brick = ((size_t)(z >> 3) * (size_t)nby + (size_t)(y >> 3)) * (size_t)nbx + (size_t)(x >> 3);
+    const unsigned sub = (((unsigned)z >> 2) & 1u) * 4u + (((unsigned)y >> 2) & 1u) * 2u + (((unsigned)x >> 2) & 1u);
+    const unsigned inner = ((unsigned)z & 3u) * 16u + ((unsigned)y & 3u) * 4u + ((unsigned)x & 3u);
+    return brick * 512u + sub * 64u + inner;
+  }
+
+  // int coordinates (read_imagei(img, int4)): out of range -> border record 0
+  __device__ __forceinline__ uint32_t fetch_i(int x, int y, int z) const {
+    if ((unsigned)x >= (unsigned)X || (unsigned)y >= (unsigned)Y || (unsigned)z >= (unsigned)Z) return 0u;
+    return rec[record_index(x, y, z, NBX, NBY)];
+  }
+  // float coordinates (read_imagei(img, smp, float4)): texel = floor(coord); out of range / NaN -> 0
+  __device__ __forceinline__ uint32_t fetch_f(float fx, float fy, float fz) const {
+    const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
+    if (!(gx >= 0.0f && gy >= 0.0f && gz >= 0.0f && gx < (float)X && gy < (float)Y && gz < (float)Z)) return 0u;
+    return rec[record_index((int)gx, (int)gy, (int)gz, NBX, NBY)];
+  }
+
+  __device__ __forceinline__ static int value_of(uint32_t r) { return (int)(int16_t)(r & 0xFFFFu); }
+  __device__ __forceinline__ static int sdf_of(uint32_t r) { return (int)(int8_t)((r >> 16) & 0xFFu); }
+  __device__ __forceinline__ static unsigned class_of(uint32_t r) { return r >> 24; }
+
+  __device__ __forceinline__ int value_at(float fx, float fy, float fz) const { return value_of(fetch_f(fx, fy, fz)); }
+  __device__ __forceinline__ int sdf_at(int x, int y, int z) const { return sdf_of(fetch_i(x, y, z)); }
+};
+
+}  // namespace clvr

@@ -7,6 +7,7 @@
 
 #include "clwh_internal.hpp"
 #include "device_math.hpp"
+#include "packed_volume.hpp"
 
 namespace clvr {
 
@@ -170,6 +171,39 @@ __device__ __forceinline__ Ray march_to_next_event(const Vol &v, const TfDev &tf
     cur.origin = cur.origin + cur.direction * step_size;
     ev = get_event_and_value<USE_GRAD>(v, tf, cur.origin, color);
     if (ev != EV_NONE) break;
+  }
+  event = ev;
+  return cur;
+}
+
+// The same march on packed records: one gather per step.  The record fetched at floor(new origin)
+// classifies the new position and carries the SDF value of the NEXT step: inside the volume
+// (0 <= coord <= dim, which `!exited_volume` guarantees) trunc == floor, coord == dim reads the border
+// record 0 on both sides, and a NaN origin stays NaN whatever the step length.  Only the first SDF
+// read of a march is at an arbitrary origin and keeps the truncating int-coordinate read.
+template <bool USE_GRAD>
+__device__ __forceinline__ Ray march_to_next_event(const VolumePacked &v, const TfDev &tf, Ray cur, int &event,
+                                                   uint32_t &color) {
+  int ev = EV_NONE;
+  int sd = v.sdf_at(f2i(cur.origin.x), f2i(cur.origin.y), f2i(cur.origin.z));
+  for (int i = 0; i < 70; ++i) {
+    const float step_size = cl_max((float)sd, 0.5f);
+    cur.origin = cur.origin + cur.direction * step_size;
+    if (exited_volume(v, cur.origin)) { ev = EV_EXIT; break; }
+    const uint32_t r = v.fetch_f(cur.origin.x, cur.origin.y, cur.origin.z);
+    if (USE_GRAD) {
+      const int gradient = (int)(short)f2i(length3(gradient_nn(v, cur.origin)));
+      if (tf_eval(tf, VolumePacked::value_of(r), gradient, color)) { ev = EV_HIT; break; }
+    } else {
+      const unsigned cls = VolumePacked::class_of(r);
+      if (cls != 0u) {
+        const TfRuleDev &rule = tf.rules[cls - 1u];
+        if (rule.flags & TF_WRITES_COLOR) color = rule.color;
+        ev = EV_HIT;
+        break;
+      }
+    }
+    sd = VolumePacked::sdf_of(r);
   }
   event = ev;
   return cur;

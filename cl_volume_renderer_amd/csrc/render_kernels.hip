@@ -18,7 +18,18 @@ __device__ __forceinline__ uint32_t xcd_contiguous_slot(uint32_t b, uint32_t nbl
   return (b & 7u) * per + (b >> 3);
 }
 
-template <bool USE_GRAD>
+template <class Vol>
+__device__ __forceinline__ Vol make_volume(const RenderArgs &a);
+template <>
+__device__ __forceinline__ VolumeLinear make_volume<VolumeLinear>(const RenderArgs &a) {
+  return VolumeLinear{a.volume, a.sdf, a.X, a.Y, a.Z};
+}
+template <>
+__device__ __forceinline__ VolumePacked make_volume<VolumePacked>(const RenderArgs &a) {
+  return VolumePacked{a.packed, a.X, a.Y, a.Z, a.NBX, a.NBY};
+}
+
+template <bool USE_GRAD, class Vol>
 __global__ __launch_bounds__(64) void k_render_v0(const RenderArgs a) {
   const uint32_t slot = xcd_contiguous_slot(blockIdx.x, a.num_blocks);
   int tx, ty;
@@ -29,7 +40,7 @@ __global__ __launch_bounds__(64) void k_render_v0(const RenderArgs a) {
   const size_t pslot = (size_t)slot * 64u + lane;
   const size_t pix = (size_t)y * (size_t)a.launch_w + x;
 
-  const VolumeLinear vol{a.volume, a.sdf, a.X, a.Y, a.Z};
+  const Vol vol = make_volume<Vol>(a);
   const f3 cam_o = f3{a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]};
   const f3 cam_d = f3{a.cam_dir[0], a.cam_dir[1], a.cam_dir[2]};
   const Ray vray = generate_ray(cam_o, cam_d, (int)x, (int)y, a.frame_w, a.frame_h);
@@ -188,11 +199,58 @@ __global__ __launch_bounds__(64) void k_accum_resolve(const float4 *__restrict__
   frame[(size_t)y * frame_w + x] = out;
 }
 
+// volume + SDF + transfer function -> packed bricked records; one wave writes one 4x4x4 sub-brick
+// (256 contiguous bytes)
+__global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
+  const size_t sub_id = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+  const size_t n_sub = (size_t)a.NBX * a.NBY * a.NBZ * 8u;
+  if (sub_id >= n_sub) return;
+  const size_t brick = sub_id >> 3;
+  const unsigned sub = (unsigned)(sub_id & 7u);
+  const int bx = (int)(brick % (size_t)a.NBX);
+  const int by = (int)((brick / (size_t)a.NBX) % (size_t)a.NBY);
+  const int bz = (int)(brick / ((size_t)a.NBX * (size_t)a.NBY));
+  const unsigned lane = threadIdx.x & 63u;
+  const int x = bx * 8 + (int)(sub & 1u) * 4 + (int)(lane & 3u);
+  const int y = by * 8 + (int)((sub >> 1) & 1u) * 4 + (int)((lane >> 2) & 3u);
+  const int z = bz * 8 + (int)((sub >> 2) & 1u) * 4 + (int)(lane >> 4);
+  uint32_t r = 0u;
+  if (x < a.X && y < a.Y && z < a.Z) {
+    const size_t i = ((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x;
+    const int value = a.volume[i];
+    const int sd = a.sdf[i];
+    unsigned cls = 0u;
+    if (!a.tf.uses_gradient) {
+      // first matching rule wins; a terminal rule (`return (cond);`) ends the evaluation
+      for (int k = 0; k < a.tf.n; ++k) {
+        const TfRuleDev &rule = a.tf.rules[k];
+        if (value >= rule.v_lo && value <= rule.v_hi) { cls = (unsigned)k + 1u; break; }
+        if (rule.flags & TF_TERMINAL) break;
+      }
+    }
+    r = ((uint32_t)value & 0xFFFFu) | (((uint32_t)sd & 0xFFu) << 16) | (cls << 24);
+  }
+  a.packed[sub_id * 64u + lane] = r;
+}
+
+hipError_t launch_repack(const RepackArgs &a, hipStream_t s) {
+  const size_t n_sub = (size_t)a.NBX * a.NBY * a.NBZ * 8u;
+  hipLaunchKernelGGL(k_repack, dim3((unsigned)((n_sub + 3u) / 4u)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_render_v0(const RenderArgs &a, hipStream_t s) {
-  if (a.tf.uses_gradient)
-    hipLaunchKernelGGL(k_render_v0<true>, dim3(a.num_blocks), dim3(64), 0, s, a);
-  else
-    hipLaunchKernelGGL(k_render_v0<false>, dim3(a.num_blocks), dim3(64), 0, s, a);
+  if (a.packed) {
+    if (a.tf.uses_gradient)
+      hipLaunchKernelGGL((k_render_v0<true, VolumePacked>), dim3(a.num_blocks), dim3(64), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_render_v0<false, VolumePacked>), dim3(a.num_blocks), dim3(64), 0, s, a);
+  } else {
+    if (a.tf.uses_gradient)
+      hipLaunchKernelGGL((k_render_v0<true, VolumeLinear>), dim3(a.num_blocks), dim3(64), 0, s, a);
+    else
+      hipLaunchKernelGGL((k_render_v0<false, VolumeLinear>), dim3(a.num_blocks), dim3(64), 0, s, a);
+  }
   return hipGetLastError();
 }
 

@@ -167,3 +167,32 @@ def test_image_space_mode_and_tile_partition(gpu_ctx, orc):
         buf.release()
         many.release()
     one.release()
+
+
+def test_linear_layout_path_agrees_with_packed_records(orc):
+    """CLWH_RENDER_PATH=linear keeps the caller's x-fastest images (the A/B arm of the layout
+    measurement in DESIGN.md); both arms must produce the same bits."""
+    import os
+
+    vol, sdf, env, tf = small_scene(orc, 48, dims=(50, 44, 37))
+    pos, d = look_at_centre(vol, [-20, 40, -20])
+    out = {}
+    for arm in ("linear", "packed"):
+        if arm == "linear":
+            os.environ["CLWH_RENDER_PATH"] = "linear"
+        else:
+            os.environ.pop("CLWH_RENDER_PATH", None)
+        ctx = ffi.Context(0)
+        g = GpuScene(ctx, vol, sdf, env, tf, (128, 128))
+        for s in scene.glibc_rand(3):
+            g.render(pos, d, s)
+        out[arm] = (g.cache.pull(), g.frame.pull())
+        g.release()
+        ctx.destroy()
+    os.environ.pop("CLWH_RENDER_PATH", None)
+    assert np.array_equal(out["linear"][0], out["packed"][0])
+    assert np.array_equal(out["linear"][1], out["packed"][1])
+    o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (128, 128))
+    for s in scene.glibc_rand(3):
+        o.render(pos, d, s)
+    assert np.array_equal(out["packed"][0], o.cache)
