@@ -25,10 +25,26 @@ struct TfDev {
 enum : uint32_t { TF_USE_GRADIENT = 1u, TF_WRITES_COLOR = 2u, TF_TERMINAL = 4u };
 
 // ---- render pass arguments
+// One hit record = one 64-byte line: what compute_light needs to start the sample's bounce paths.
+struct HitRec {
+  float origin[3];     // hit_information.origin (position of the primary Hit event)
+  float direction[3];  // hit_information.direction (the camera ray's direction)
+  float normal[3];     // -normalize(gradient) at the hit (ray_marching.cl:42)
+  uint32_t color;      // transfer-function colour of the hit: r | g<<8 | b<<16 | roughness<<24
+  int32_t entry_lo;    // voxel-cache entry (y-major), or -2 when the entry lies outside the cache
+  int32_t entry_hi;
+  uint32_t xy;         // global pixel: x | y<<16  (feeds the per-pixel RNG, utility_sampling.cl:41)
+  uint32_t pslot;      // tile-major pixel slot of this rank (accumulation / scratch index)
+  uint32_t pad[2];
+};
+static_assert(sizeof(HitRec) == 64, "HitRec must be one 64-byte line");
+
+enum : uint32_t { PIX_HIT = 0x80000000u };  // pix_slot: PIX_HIT | hit index, else the miss colour (rgb)
+
 struct RenderArgs {
-  const int16_t *volume;   // linear x-fastest [z][y][x]
-  const int8_t *sdf;       // same layout
   int32_t X, Y, Z;
+  const uint32_t *packed;  // bricked {value, sdf, class} records (packed_volume.hpp)
+  int32_t NBX, NBY;
   const uint32_t *env;     // RGBA8 packed, row-major
   int32_t env_w, env_h;
   uint32_t *cache;         // voxel cache as 2 x u32 per entry
@@ -40,15 +56,17 @@ struct RenderArgs {
   int32_t tile_rank, tile_world;
   float cam_pos[3];
   float cam_dir[3];
-  int32_t seed;
   int32_t mode;            // clwh_accum_mode
   float4 *accum;           // tile-major float4 per pixel slot (mode 1)
-  int64_t *hit_slot;       // tile-major scratch: cache entry or -1
+  uint32_t *pix_slot;      // tile-major, per pixel: PIX_HIT | hit index, or the miss colour
+  HitRec *hits;            // compacted primary hits of this camera
+  uint32_t *counters;      // [0] number of hits (k_primary), [1] work-queue head (k_bounce)
+  uint32_t n_hits;         // host copy of counters[0] (valid for k_bounce / k_resolve)
   int64_t *hit_index_out;  // optional, row-major over launch_w x launch_h
-  uint32_t *contrib_out;   // optional, row-major uint32[4]
-  uint32_t num_blocks;     // grid size (tile slots)
-  const uint32_t *packed;  // bricked {value, sdf, class} records (packed_volume.hpp); nullptr = linear path
-  int32_t NBX, NBY;
+  uint32_t *contrib_out;   // optional, row-major uint32[4] (single seed)
+  uint32_t num_tile_slots; // tile slots of this rank
+  int32_t n_seeds;
+  int32_t seeds[CLWH_MAX_SEEDS];
   TfDev tf;
 };
 
@@ -77,11 +95,11 @@ struct SdfArgs {
 };
 
 // host-side launchers implemented in the .hip files
-hipError_t launch_render_v0(const RenderArgs &a, hipStream_t s);
 hipError_t launch_repack(const RepackArgs &a, hipStream_t s);
+hipError_t launch_primary(const RenderArgs &a, hipStream_t s);
+hipError_t launch_bounce(const RenderArgs &a, hipStream_t s);
 hipError_t launch_resolve(const RenderArgs &a, hipStream_t s);
-hipError_t launch_accum_resolve(const float4 *accum_all, int32_t tile_world, int32_t width, int32_t height,
-                                uint32_t *frame, int32_t frame_w, int32_t frame_h, hipStream_t s);
+hipError_t launch_accum_resolve(const RenderArgs &a, const float4 *accum_all, hipStream_t s);
 hipError_t launch_sdf_base(const SdfArgs &a, hipStream_t s);
 hipError_t launch_sdf_layer(const SdfArgs &a, hipStream_t s);
 
@@ -92,9 +110,22 @@ struct clwh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
-  // scratch
-  void *hit_scratch = nullptr;
-  size_t hit_scratch_bytes = 0;
+  // per-camera primary hits (derived data, rebuilt when the key below changes)
+  uint32_t *pix_slot = nullptr;
+  size_t pix_slot_bytes = 0;
+  clvr::HitRec *hits = nullptr;
+  size_t hits_bytes = 0;
+  uint32_t *render_counters = nullptr;  // 2 x u32 on the device
+  bool primary_valid = false;
+  uint32_t primary_n_hits = 0;
+  struct PrimaryKey {
+    float cam_pos[3], cam_dir[3];
+    int32_t frame_w, frame_h, launch_w, launch_h, tile_rank, tile_world;
+    int64_t cache_entries;
+    int32_t mode;
+    uint64_t packed_generation;
+  } primary_key{};
+  uint64_t packed_generation = 0;
   int32_t *sdf_counters = nullptr;  // 2 x 160 ints (counters, done)
   int8_t *sdf_pong = nullptr;
   size_t sdf_pong_bytes = 0;
@@ -105,7 +136,7 @@ struct clwh_ctx {
   uint64_t packed_vol_ver = 0, packed_sdf_ver = 0;
   clvr::TfDev packed_tf{};
   bool packed_valid = false;
-  bool use_linear_path = false;  // CLWH_RENDER_PATH=linear: A/B switch for measurements
+
   // timing: one HIP event pair per clwh_render, recorded on the context's stream around the
   // dominant kernel and read back (without a sync per pass) by clwh_ctx_timing_read
   bool timing = false;

@@ -71,8 +71,6 @@ int clwh_ctx_create_on_stream(int device, void *hip_stream, clwh_ctx **out) {
   c->device = device;
   c->stream = (hipStream_t)hip_stream;
   c->own_stream = false;
-  const char *path = std::getenv("CLWH_RENDER_PATH");
-  c->use_linear_path = path && !std::strcmp(path, "linear");
   *out = c;
   return CLWH_OK;
 }
@@ -97,7 +95,9 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
   if (!ctx) return CLWH_ERR_INVALID_VALUE;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
-  if (ctx->hit_scratch) (void)hipFree(ctx->hit_scratch);
+  if (ctx->pix_slot) (void)hipFree(ctx->pix_slot);
+  if (ctx->hits) (void)hipFree(ctx->hits);
+  if (ctx->render_counters) (void)hipFree(ctx->render_counters);
   if (ctx->sdf_counters) (void)hipFree(ctx->sdf_counters);
   if (ctx->sdf_pong) (void)hipFree(ctx->sdf_pong);
   if (ctx->packed) (void)hipFree(ctx->packed);
@@ -336,19 +336,6 @@ static bool is_image(const clwh_mem *m, int dims_n, int channels, int elem_kind)
   return true;
 }
 
-static int ensure_scratch(clwh_ctx *ctx, size_t bytes) {
-  if (ctx->hit_scratch_bytes >= bytes) return CLWH_OK;
-  if (ctx->hit_scratch) {
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(ctx->hit_scratch));
-    ctx->hit_scratch = nullptr;
-    ctx->hit_scratch_bytes = 0;
-  }
-  HIP_TRY(hipMalloc(&ctx->hit_scratch, bytes));
-  ctx->hit_scratch_bytes = bytes;
-  return CLWH_OK;
-}
-
 // (re)build the packed {value, sdf, class} records when the volume, the SDF or the TF changed
 static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *sdf, const TfDev &tf) {
   const int X = (int)volume->dims[0], Y = (int)volume->dims[1], Z = (int)volume->dims[2];
@@ -384,7 +371,40 @@ static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *
   ctx->packed_sdf_ver = sdf->version;
   ctx->packed_tf = tf;
   ctx->packed_valid = true;
+  ctx->packed_generation++;
   return CLWH_OK;
+}
+
+static int grow(clwh_ctx *ctx, void **p, size_t *have, size_t need) {
+  if (*have >= need) return CLWH_OK;
+  if (*p) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    *have = 0;
+  }
+  HIP_TRY(hipMalloc(p, need));
+  *have = need;
+  return CLWH_OK;
+}
+
+// fill the parts of RenderArgs that describe the frame / tile partition / camera
+static void describe_frame(RenderArgs &a, int32_t launch_w, int32_t launch_h, int32_t frame_w, int32_t frame_h,
+                           int32_t rank, int32_t world, const float cam_pos[3], const float cam_dir[3]) {
+  a.launch_w = launch_w;
+  a.launch_h = launch_h;
+  a.frame_w = frame_w;
+  a.frame_h = frame_h;
+  a.tiles_x = launch_w / 8;
+  a.tiles_y = launch_h / 8;
+  a.tile_rank = rank;
+  a.tile_world = world;
+  a.tiles_per_row = (a.tiles_x + world - 1) / world;
+  a.num_tile_slots = (uint32_t)a.tiles_y * (uint32_t)a.tiles_per_row;
+  for (int q = 0; q < 3; ++q) {
+    a.cam_pos[q] = cam_pos[q];
+    a.cam_dir[q] = cam_dir[q];
+  }
 }
 
 int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
@@ -397,43 +417,28 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   for (int q = 0; q < 3; ++q)
     if (d->volume->dims[q] != d->sdf->dims[q]) return CLWH_ERR_SIZE_MISMATCH;
   if (d->width == 0 || d->height == 0 || (d->width % 8) != 0 || (d->height % 8) != 0) return CLWH_ERR_BAD_NDRANGE;
+  if (d->width > 65535u || d->height > 65535u) return CLWH_ERR_BAD_NDRANGE;  // pixel ids are packed x | y << 16
   if (d->volume->dims[0] > 0x7fffffffu || d->volume->dims[1] > 0x7fffffffu || d->volume->dims[2] > 0x7fffffffu)
     return CLWH_ERR_INVALID_VALUE;
   const int world = d->tile_world < 1 ? 1 : d->tile_world;
   if (d->tile_rank < 0 || d->tile_rank >= world) return CLWH_ERR_INVALID_VALUE;
+  if (d->n_seeds < 0 || d->n_seeds > CLWH_MAX_SEEDS) return CLWH_ERR_INVALID_VALUE;
+  if (d->n_seeds > 1 && d->contrib) return CLWH_ERR_BAD_ARGS;  // per-pixel contribution output: one seed
 
   RenderArgs a;
   std::memset(&a, 0, sizeof a);
-  a.volume = (const int16_t *)d->volume->dptr;
-  a.sdf = (const int8_t *)d->sdf->dptr;
   a.X = (int32_t)d->volume->dims[0];
   a.Y = (int32_t)d->volume->dims[1];
   a.Z = (int32_t)d->volume->dims[2];
   a.env = (const uint32_t *)d->env->dptr;
   a.env_w = (int32_t)d->env->dims[0];
   a.env_h = (int32_t)d->env->dims[1];
-  a.launch_w = (int32_t)d->width;
-  a.launch_h = (int32_t)d->height;
-  if (d->frame) {
-    a.frame = (uint32_t *)d->frame->dptr;
-    a.frame_w = (int32_t)d->frame->dims[0];
-    a.frame_h = (int32_t)d->frame->dims[1];
-  } else {
-    a.frame = nullptr;
-    a.frame_w = a.launch_w;  // get_image_width(frame) of the frame the caller will resolve into
-    a.frame_h = a.launch_h;
-  }
-  a.tiles_x = a.launch_w / 8;
-  a.tiles_y = a.launch_h / 8;
-  a.tile_rank = d->tile_rank;
-  a.tile_world = world;
-  a.tiles_per_row = (a.tiles_x + world - 1) / world;
-  a.num_blocks = (uint32_t)a.tiles_y * (uint32_t)a.tiles_per_row;
-  for (int q = 0; q < 3; ++q) {
-    a.cam_pos[q] = d->cam_pos[q];
-    a.cam_dir[q] = d->cam_dir[q];
-  }
-  a.seed = d->seed;
+  // get_image_width/height(frame): the frame IMAGE's dims (the reference allocates 2048x1024 whatever
+  // the launch size); without a frame, the launch size
+  const int32_t fw = d->frame ? (int32_t)d->frame->dims[0] : (int32_t)d->width;
+  const int32_t fh = d->frame ? (int32_t)d->frame->dims[1] : (int32_t)d->height;
+  describe_frame(a, (int32_t)d->width, (int32_t)d->height, fw, fh, d->tile_rank, world, d->cam_pos, d->cam_dir);
+  a.frame = d->frame ? (uint32_t *)d->frame->dptr : nullptr;
   a.mode = d->accum_mode;
   if (a.mode == CLWH_ACCUM_VOXEL_CACHE) {
     if (!d->buffer_volume || d->buffer_volume->bytes < 8) return CLWH_ERR_BAD_ARGS;
@@ -455,27 +460,68 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     if (d->contrib->bytes < npx * 16) return CLWH_ERR_SIZE_MISMATCH;
     a.contrib_out = (uint32_t *)d->contrib->dptr;
   }
+  if (d->n_seeds > 0) {
+    a.n_seeds = d->n_seeds;
+    for (int q = 0; q < d->n_seeds; ++q) a.seeds[q] = d->seeds[q];
+  } else {
+    a.n_seeds = 1;
+    a.seeds[0] = d->seed;
+  }
   tf_to_dev(k->tf, a.tf);
 
   HIP_TRY(hipSetDevice(ctx->device));
-  int rc = ensure_scratch(ctx, (size_t)a.num_blocks * 64u * sizeof(int64_t));
+  int rc = ensure_packed(ctx, d->volume, d->sdf, a.tf);
   if (rc != CLWH_OK) return rc;
-  a.hit_slot = (int64_t *)ctx->hit_scratch;
-  if (!ctx->use_linear_path) {
-    rc = ensure_packed(ctx, d->volume, d->sdf, a.tf);
-    if (rc != CLWH_OK) return rc;
-    a.packed = ctx->packed;
-    a.NBX = (a.X + 7) / 8;
-    a.NBY = (a.Y + 7) / 8;
-  }
+  a.packed = ctx->packed;
+  a.NBX = (a.X + 7) / 8;
+  a.NBY = (a.Y + 7) / 8;
 
+  // ---- primary hits of this camera: rebuilt only when something they depend on changed
+  const size_t slots = (size_t)a.num_tile_slots * 64u;
+  rc = grow(ctx, (void **)&ctx->pix_slot, &ctx->pix_slot_bytes, slots * sizeof(uint32_t));
+  if (rc != CLWH_OK) return rc;
+  rc = grow(ctx, (void **)&ctx->hits, &ctx->hits_bytes, slots * sizeof(HitRec));
+  if (rc != CLWH_OK) return rc;
+  if (!ctx->render_counters) HIP_TRY(hipMalloc((void **)&ctx->render_counters, 2 * sizeof(uint32_t)));
+  a.pix_slot = ctx->pix_slot;
+  a.hits = ctx->hits;
+  a.counters = ctx->render_counters;
+
+  clwh_ctx::PrimaryKey key;
+  std::memset(&key, 0, sizeof key);
+  for (int q = 0; q < 3; ++q) {
+    key.cam_pos[q] = a.cam_pos[q];
+    key.cam_dir[q] = a.cam_dir[q];
+  }
+  key.frame_w = a.frame_w; key.frame_h = a.frame_h;
+  key.launch_w = a.launch_w; key.launch_h = a.launch_h;
+  key.tile_rank = a.tile_rank; key.tile_world = a.tile_world;
+  key.cache_entries = a.cache_entries;
+  key.mode = a.mode;
+  key.packed_generation = ctx->packed_generation;
+  if (!ctx->primary_valid || std::memcmp(&key, &ctx->primary_key, sizeof key) != 0 || a.hit_index_out) {
+    ctx->primary_valid = false;
+    HIP_TRY(hipMemsetAsync(ctx->render_counters, 0, 2 * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(launch_primary(a, ctx->stream));
+    uint32_t n_hits = 0;
+    HIP_TRY(hipMemcpyAsync(&n_hits, ctx->render_counters, sizeof n_hits, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // once per camera / scene change: sizes the bounce grid
+    ctx->primary_n_hits = n_hits;
+    ctx->primary_key = key;
+    ctx->primary_valid = true;
+  }
+  a.n_hits = ctx->primary_n_hits;
+
+  // ---- the pass: every (hit, seed) item
+  HIP_TRY(hipMemsetAsync(ctx->render_counters + 1, 0, sizeof(uint32_t), ctx->stream));
+  if (a.contrib_out) HIP_TRY(hipMemsetAsync(a.contrib_out, 0, npx * 16, ctx->stream));  // misses contribute nothing
   hipEvent_t ev_b = nullptr, ev_e = nullptr;
   if (ctx->timing) {
     rc = timing_slot(ctx, &ev_b, &ev_e);
     if (rc != CLWH_OK) return rc;
     HIP_TRY(hipEventRecord(ev_b, ctx->stream));
   }
-  HIP_TRY(launch_render_v0(a, ctx->stream));
+  HIP_TRY(launch_bounce(a, ctx->stream));
   if (ctx->timing) HIP_TRY(hipEventRecord(ev_e, ctx->stream));
   if (d->write_frame && a.frame) HIP_TRY(launch_resolve(a, ctx->stream));
   if (d->frame) d->frame->version++;
@@ -483,17 +529,30 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
 }
 
 int clwh_accum_resolve(clwh_ctx *ctx, clwh_mem *accum_all, int32_t tile_world, uint32_t width, uint32_t height,
-                       clwh_mem *frame) {
-  if (!ctx || !accum_all || !frame || tile_world < 1) return CLWH_ERR_INVALID_VALUE;
-  if (!is_image(frame, 2, 4, CLWH_ELEM_U8)) return CLWH_ERR_BAD_ARGS;
+                       clwh_mem *frame, clwh_mem *env, const float cam_pos[3], const float cam_dir[3]) {
+  if (!ctx || !accum_all || !frame || !env || !cam_pos || !cam_dir || tile_world < 1) return CLWH_ERR_INVALID_VALUE;
+  if (!is_image(frame, 2, 4, CLWH_ELEM_U8) || !is_image(env, 2, 4, CLWH_ELEM_U8)) return CLWH_ERR_BAD_ARGS;
   if (width == 0 || height == 0 || (width % 8) || (height % 8)) return CLWH_ERR_BAD_NDRANGE;
   const int64_t need = clwh_accum_len(width, height, tile_world) * 16 * tile_world;
   if ((int64_t)accum_all->bytes < need) return CLWH_ERR_SIZE_MISMATCH;
+  RenderArgs a;
+  std::memset(&a, 0, sizeof a);
+  describe_frame(a, (int32_t)width, (int32_t)height, (int32_t)frame->dims[0], (int32_t)frame->dims[1], 0, tile_world,
+                 cam_pos, cam_dir);
+  a.frame = (uint32_t *)frame->dptr;
+  a.env = (const uint32_t *)env->dptr;
+  a.env_w = (int32_t)env->dims[0];
+  a.env_h = (int32_t)env->dims[1];
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(launch_accum_resolve((const float4 *)accum_all->dptr, tile_world, (int32_t)width, (int32_t)height,
-                               (uint32_t *)frame->dptr, (int32_t)frame->dims[0], (int32_t)frame->dims[1],
-                               ctx->stream));
+  HIP_TRY(launch_accum_resolve(a, (const float4 *)accum_all->dptr, ctx->stream));
   frame->version++;
+  return CLWH_OK;
+}
+
+int clwh_ctx_invalidate_derived(clwh_ctx *ctx) {
+  if (!ctx) return CLWH_ERR_INVALID_VALUE;
+  ctx->packed_valid = false;
+  ctx->primary_valid = false;
   return CLWH_OK;
 }
 

@@ -1,11 +1,31 @@
-// render_kernels.hip -- the `render` pass for gfx950 (one sample per pixel per pass).
+// render_kernels.hip -- the `render` pass for gfx950, organised for wave64 hardware.
 //
-// v0: one work-group = one wave64 = one 8x8 pixel tile (the reference's own work-group shape,
-// app/renderer.cpp:145), every lane walks its pixel's whole path (ray_marching.cl:10-101, 152-199),
-// volume / SDF in the caller's linear layout.  The frame is NOT read back from the cache while other
-// lanes are still adding to it (the reference's race): hit pixels record their cache
-// entry and a second kernel resolves them after the pass, which is one legal outcome of that race
-// and is deterministic.
+// The reference runs one work-item per pixel through the whole path (ray_marching.cl:152-199):
+// camera ray -> box entry -> primary march -> on a Hit, two distribution rays of up to three
+// marches each -> accumulate -> read the accumulator back.  On a 64-wide wave that shape wastes the
+// machine twice: only a fraction of the pixels hit anything, and the lanes that do walk paths of
+// very different lengths.  Here the pass is split where the divergence is:
+//
+//   k_repack   (when volume / SDF / TF changed)  packed bricked {value, sdf, class} records
+//   k_primary  (when the camera changed)         one lane per pixel: ray, box entry, primary march;
+//                                                hits are compacted into 64-byte records with a
+//                                                wave ballot + prefix (one atomic per wave);
+//                                                misses keep their environment colour
+//   k_bounce   (every pass, 1..16 seeds)         persistent waves pull (hit, seed) items from a work
+//                                                queue; each lane runs the sample's two
+//                                                distribution rays as a small state machine; lanes
+//                                                that finish are refilled by ballot/prefix
+//                                                compaction; march steps and event handling run in
+//                                                separate wave-wide phases so both stay dense
+//   k_resolve  (when a frame is wanted)          read the accumulator AFTER the pass (deterministic;
+//                                                one legal outcome of the reference's race, SURVEY
+//                                                fact 4), tone curve, RGBA8
+//
+// The primary march does not depend on the pass's seed, so its result is kept while camera, volume,
+// SDF and transfer function stay the same; per sample, every float operation is the one the reference
+// kernel performs, in the same order (device_math.hpp), only scheduled differently.
+#include <algorithm>
+
 #include "render_device.hpp"
 
 namespace clvr {
@@ -18,187 +38,17 @@ __device__ __forceinline__ uint32_t xcd_contiguous_slot(uint32_t b, uint32_t nbl
   return (b & 7u) * per + (b >> 3);
 }
 
-template <class Vol>
-__device__ __forceinline__ Vol make_volume(const RenderArgs &a);
-template <>
-__device__ __forceinline__ VolumeLinear make_volume<VolumeLinear>(const RenderArgs &a) {
-  return VolumeLinear{a.volume, a.sdf, a.X, a.Y, a.Z};
-}
-template <>
-__device__ __forceinline__ VolumePacked make_volume<VolumePacked>(const RenderArgs &a) {
+__device__ __forceinline__ VolumePacked make_volume(const RenderArgs &a) {
   return VolumePacked{a.packed, a.X, a.Y, a.Z, a.NBX, a.NBY};
 }
 
-template <bool USE_GRAD, class Vol>
-__global__ __launch_bounds__(64) void k_render_v0(const RenderArgs a) {
-  const uint32_t slot = xcd_contiguous_slot(blockIdx.x, a.num_blocks);
-  int tx, ty;
-  if (!tile_from_slot(a, slot, tx, ty)) return;
-  const uint32_t lane = threadIdx.x;
-  const uint32_t x = (uint32_t)tx * 8u + (lane & 7u);
-  const uint32_t y = (uint32_t)ty * 8u + (lane >> 3);
-  const size_t pslot = (size_t)slot * 64u + lane;
-  const size_t pix = (size_t)y * (size_t)a.launch_w + x;
-
-  const Vol vol = make_volume<Vol>(a);
-  const f3 cam_o = f3{a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]};
-  const f3 cam_d = f3{a.cam_dir[0], a.cam_dir[1], a.cam_dir[2]};
-  const Ray vray = generate_ray(cam_o, cam_d, (int)x, (int)y, a.frame_w, a.frame_h);
-  const float dx = (float)a.X, dy = (float)a.Y, dz = (float)a.Z;
-
-  int64_t hit_entry = -1;  // what resolve reads: entry, -1 = miss, -2 = hit outside the cache
-  int64_t raw_entry = -1;  // parity output: the entry as computed, valid or not
-  uint32_t contrib_r = 0, contrib_g = 0, contrib_b = 0, granted_flag = 0;
-
-  bool cut_ok;
-  f3 cut_point;
-  if (!(within(vray.origin.x, dx) && within(vray.origin.y, dy) && within(vray.origin.z, dz))) {
-    cut_ok = cut_box(dx, dy, dz, vray, cut_point);
-  } else {
-    cut_ok = true;
-    cut_point = vray.origin;
-  }
-
-  bool hit = false;
-  if (cut_ok) {
-    Ray current_ray{cut_point, vray.direction};
-    uint32_t current_color = 0u;
-    int ev;
-    current_ray = march_to_next_event<USE_GRAD>(vol, a.tf, current_ray, ev, current_color);
-    if (ev == EV_HIT) {
-      hit = true;
-      const Ray hit_information = current_ray;
-      hit_entry = cache_entry_of(a.X, a.Z, current_ray.origin);
-      raw_entry = hit_entry;
-      const bool entry_ok = hit_entry >= 0 && hit_entry < a.cache_entries;
-      bool granted;
-      if (a.mode == CLWH_ACCUM_VOXEL_CACHE)
-        granted = entry_ok && cache_take_token(a.cache, hit_entry, 256u);
-      else
-        granted = true;
-
-      if (granted) {
-        const f3 normal = -normalize3(gradient_nn(vol, current_ray.origin));
-        float r_energy = (float)(current_color & 255u) / 255.0f;
-        float g_energy = (float)((current_color >> 8) & 255u) / 255.0f;
-        float b_energy = (float)((current_color >> 16) & 255u) / 255.0f;
-        uint32_t bv_r = 0, bv_g = 0, bv_b = 0;
-
-        for (int o = 1; o <= 2; ++o) {  // dist_count = 2
-          {
-            const float roughness = (float)(current_color >> 24) / 255.0f;
-            Ray nr;
-            nr.origin = hit_information.origin + hit_information.direction;
-            nr.direction = hemisphere_reflective(x, y, normal, a.seed + o, roughness);
-            current_ray = nr;
-          }
-          current_ray.origin = current_ray.origin + normal * 2.0f;
-          float atten = fabsf(dot3(current_ray.direction, normal));
-
-          for (int i = 8; i <= 10; ++i) {  // path_length = 3
-            current_ray = march_to_next_event<USE_GRAD>(vol, a.tf, current_ray, ev, current_color);
-            if (ev == EV_EXIT) {
-              const float factor = 8.0f / (float)i;
-              const uint32_t light = sample_environment_map(a.env, a.env_w, a.env_h, current_ray.direction);
-              // uint += float: promote, add, truncate back
-              bv_r = f2u((float)bv_r + atten * r_energy * (float)(light & 255u) * factor / 1.0f);
-              bv_g = f2u((float)bv_g + atten * g_energy * (float)((light >> 8) & 255u) * factor / 1.0f);
-              bv_b = f2u((float)bv_b + atten * b_energy * (float)((light >> 16) & 255u) * factor / 1.0f);
-              break;
-            } else if (ev == EV_HIT) {
-              const f3 normal2 = -normalize3(gradient_nn(vol, current_ray.origin));
-              const float roughness = (float)(current_color >> 24) / 255.0f;
-              Ray nr;
-              nr.origin = current_ray.origin + current_ray.direction;
-              nr.direction = hemisphere_reflective(x, y, normal2, a.seed + o + i, roughness);
-              current_ray = nr;
-              current_ray.origin = current_ray.origin + normal2 * 2.0f;
-              atten *= fabsf(dot3(current_ray.direction, normal2));
-              r_energy *= (float)(current_color & 255u) / 255.0f;
-              g_energy *= (float)((current_color >> 8) & 255u) / 255.0f;
-              b_energy *= (float)((current_color >> 16) & 255u) / 255.0f;
-            }
-          }
-        }
-        bv_r /= 2u; bv_g /= 2u; bv_b /= 2u;
-        contrib_r = bv_r & 0xFFFFu; contrib_g = bv_g & 0xFFFFu; contrib_b = bv_b & 0xFFFFu;
-        granted_flag = 1u;
-        if (a.mode == CLWH_ACCUM_VOXEL_CACHE) {
-          cache_add(a.cache, hit_entry, bv_r, bv_g, bv_b, 0u);
-        } else {
-          float4 acc = a.accum[pslot];
-          acc.x += (float)contrib_r; acc.y += (float)contrib_g; acc.z += (float)contrib_b; acc.w += 1.0f;
-          a.accum[pslot] = acc;
-        }
-      }
-      if (a.mode == CLWH_ACCUM_VOXEL_CACHE && !entry_ok) hit_entry = -2;  // hit, but nothing to read
-      if (a.mode == CLWH_ACCUM_IMAGE_SPACE) hit_entry = 0;                 // resolve reads accum, not the cache
-    }
-  }
-
-  if (!hit) {
-    // miss: environment colour, alpha 200 (ray_marching.cl:172-178, 188-195)
-    const uint32_t e = sample_environment_map(a.env, a.env_w, a.env_h, vray.direction);
-    const uint32_t color = (e & 0x00FFFFFFu) | (200u << 24);
-    if (a.frame && x < (uint32_t)a.frame_w && y < (uint32_t)a.frame_h) a.frame[(size_t)y * a.frame_w + x] = color;
-    if (a.mode == CLWH_ACCUM_IMAGE_SPACE)
-      a.accum[pslot] = make_float4((float)(e & 255u), (float)((e >> 8) & 255u), (float)((e >> 16) & 255u), 0.0f);
-  }
-  a.hit_slot[pslot] = hit_entry;
-  if (a.hit_index_out) a.hit_index_out[pix] = raw_entry;
-  if (a.contrib_out) {
-    uint32_t *q = a.contrib_out + pix * 4;
-    q[0] = contrib_r; q[1] = contrib_g; q[2] = contrib_b; q[3] = granted_flag;
-  }
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ unsigned prefix_count(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
+__device__ __forceinline__ unsigned lane_id() { return prefix_count(~0ull); }
 
-// resolve: every hit pixel reads its accumulator after the whole pass (ray_marching.cl:82-99)
-__global__ __launch_bounds__(64) void k_resolve(const RenderArgs a) {
-  const uint32_t slot = blockIdx.x;
-  int tx, ty;
-  if (!tile_from_slot(a, slot, tx, ty)) return;
-  const uint32_t lane = threadIdx.x;
-  const uint32_t x = (uint32_t)tx * 8u + (lane & 7u);
-  const uint32_t y = (uint32_t)ty * 8u + (lane >> 3);
-  if (x >= (uint32_t)a.frame_w || y >= (uint32_t)a.frame_h) return;
-  const size_t pslot = (size_t)slot * 64u + lane;
-  const int64_t e = a.hit_slot[pslot];
-  if (e == -1) return;  // miss: env colour already written
-  uint32_t out;
-  if (a.mode == CLWH_ACCUM_VOXEL_CACHE) {
-    if (e < 0) {
-      out = 1u << 24;
-    } else {
-      const uint2 w = *reinterpret_cast<const uint2 *>(a.cache + e * 2);
-      out = tone_map_rgba8(w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16);
-    }
-  } else {
-    const float4 acc = a.accum[pslot];
-    out = tone_map_rgba8((uint32_t)acc.x, (uint32_t)acc.y, (uint32_t)acc.z, (uint32_t)acc.w);
-  }
-  a.frame[(size_t)y * a.frame_w + x] = out;
-}
-
-// gathered image-space accumulation (all ranks' tile-major buffers, concatenated) -> RGBA8 frame
-__global__ __launch_bounds__(64) void k_accum_resolve(const float4 *__restrict__ accum_all, int tile_world,
-                                                      int tiles_x, int tiles_y, int tiles_per_row,
-                                                      uint32_t *frame, int frame_w, int frame_h) {
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int owner = (tx + ty) % tile_world;
-  const size_t slot = (size_t)ty * tiles_per_row + (size_t)(tx / tile_world);
-  const size_t per_rank = (size_t)tiles_y * tiles_per_row * 64u;
-  const uint32_t lane = threadIdx.x;
-  const float4 acc = accum_all[(size_t)owner * per_rank + slot * 64u + lane];
-  const uint32_t x = (uint32_t)tx * 8u + (lane & 7u), y = (uint32_t)ty * 8u + (lane >> 3);
-  if (x >= (uint32_t)frame_w || y >= (uint32_t)frame_h) return;
-  uint32_t out;
-  if (acc.w == 0.0f)
-    out = (uint32_t)acc.x | ((uint32_t)acc.y << 8) | ((uint32_t)acc.z << 16) | (200u << 24);
-  else
-    out = tone_map_rgba8((uint32_t)acc.x, (uint32_t)acc.y, (uint32_t)acc.z, (uint32_t)acc.w);
-  frame[(size_t)y * frame_w + x] = out;
-}
-
+// ------------------------------------------------------------------------------------------------
 // volume + SDF + transfer function -> packed bricked records; one wave writes one 4x4x4 sub-brick
 // (256 contiguous bytes)
 __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
@@ -233,38 +83,401 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
   a.packed[sub_id * 64u + lane] = r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_primary: ray_marching.cl:152-186 up to (and including) the first march_to_next_event of
+// compute_light (:33), plus the hit's normal (:42).  One wave = one 8x8 pixel tile.
+template <bool USE_GRAD>
+__global__ __launch_bounds__(64) void k_primary(const RenderArgs a) {
+  const uint32_t slot = xcd_contiguous_slot(blockIdx.x, a.num_tile_slots);
+  int tx, ty;
+  if (!tile_from_slot(a, slot, tx, ty)) return;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t x = (uint32_t)tx * 8u + (lane & 7u);
+  const uint32_t y = (uint32_t)ty * 8u + (lane >> 3);
+  const uint32_t pslot = slot * 64u + lane;
+
+  const VolumePacked vol = make_volume(a);
+  const f3 cam_o = f3{a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]};
+  const f3 cam_d = f3{a.cam_dir[0], a.cam_dir[1], a.cam_dir[2]};
+  const Ray vray = generate_ray(cam_o, cam_d, (int)x, (int)y, a.frame_w, a.frame_h);
+  const float dx = (float)a.X, dy = (float)a.Y, dz = (float)a.Z;
+
+  bool cut_ok;
+  f3 cut_point;
+  if (!(within(vray.origin.x, dx) && within(vray.origin.y, dy) && within(vray.origin.z, dz))) {
+    cut_ok = cut_box(dx, dy, dz, vray, cut_point);
+  } else {
+    cut_ok = true;
+    cut_point = vray.origin;
+  }
+
+  bool hit = false;
+  Ray current_ray{cut_point, vray.direction};
+  uint32_t current_color = 0u;
+  if (cut_ok) {
+    int ev;
+    current_ray = march_to_next_event<USE_GRAD>(vol, a.tf, current_ray, ev, current_color);
+    hit = (ev == EV_HIT);
+  }
+
+  // wave-level compaction of the hits: one atomic per wave, prefix of the ballot per lane
+  const unsigned long long hit_mask = __ballot(hit);
+  uint32_t base = 0u;
+  if (hit_mask != 0ull) {
+    const int leader = __ffsll((long long)hit_mask) - 1;
+    if ((int)lane == leader) base = atomicAdd(&a.counters[0], (uint32_t)__popcll(hit_mask));
+    base = __shfl(base, leader);
+  }
+
+  int64_t raw_entry = -1;
+  if (hit) {
+    const uint32_t h = base + prefix_count(hit_mask);
+    const f3 normal = -normalize3(gradient_nn(vol, current_ray.origin));
+    raw_entry = cache_entry_of(a.X, a.Z, current_ray.origin);
+    int64_t entry = raw_entry;
+    if (a.mode == CLWH_ACCUM_VOXEL_CACHE && !(entry >= 0 && entry < a.cache_entries)) entry = -2;
+    uint4 q0, q1, q2, q3;
+    q0.x = __float_as_uint(current_ray.origin.x); q0.y = __float_as_uint(current_ray.origin.y);
+    q0.z = __float_as_uint(current_ray.origin.z); q0.w = __float_as_uint(current_ray.direction.x);
+    q1.x = __float_as_uint(current_ray.direction.y); q1.y = __float_as_uint(current_ray.direction.z);
+    q1.z = __float_as_uint(normal.x); q1.w = __float_as_uint(normal.y);
+    q2.x = __float_as_uint(normal.z); q2.y = current_color;
+    q2.z = (uint32_t)((uint64_t)entry & 0xFFFFFFFFull); q2.w = (uint32_t)((uint64_t)entry >> 32);
+    q3.x = x | (y << 16); q3.y = pslot; q3.z = 0u; q3.w = 0u;
+    uint4 *dst = reinterpret_cast<uint4 *>(&a.hits[h]);
+    dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
+    a.pix_slot[pslot] = PIX_HIT | h;
+  } else {
+    // miss: environment colour of the camera ray (ray_marching.cl:172-178, 188-195)
+    const uint32_t e = sample_environment_map(a.env, a.env_w, a.env_h, vray.direction);
+    a.pix_slot[pslot] = e & 0x00FFFFFFu;
+  }
+  if (a.hit_index_out) a.hit_index_out[(size_t)y * (size_t)a.launch_w + x] = raw_entry;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_bounce: ray_marching.cl:39-77 for every (hit, seed) item.
+//
+// Lane state machine.  MARCH lanes take march steps; a lane that reaches an event (Hit / Exit /
+// 70 steps, or a freshly fetched item) parks in EVENT until the wave runs its event phase; IDLE
+// lanes have no item.
+enum : int { ST_IDLE = 0, ST_MARCH = 1, ST_EVENT = 2 };
+enum : int { EV_START = 3 };            // a freshly fetched item: start distribution ray 1
+constexpr int kStepPhaseMinLanes = 24;  // keep stepping while at least this many lanes march
+constexpr int kRefillMinLanes = 16;     // refill when at least this many lanes are idle
+
+template <int MODE>
+__device__ __forceinline__ void finish_item(const RenderArgs &a, int64_t entry, uint32_t pslot, uint32_t gx,
+                                            uint32_t gy, uint32_t bv_r, uint32_t bv_g, uint32_t bv_b) {
+  // ray_marching.cl:75-76: halve (dist_count = 2), then add
+  const uint32_t cr = (bv_r / 2u) & 0xFFFFu, cg = (bv_g / 2u) & 0xFFFFu, cb = (bv_b / 2u) & 0xFFFFu;
+  if (MODE == CLWH_ACCUM_VOXEL_CACHE) {
+    cache_add(a.cache, entry, cr, cg, cb, 0u);
+  } else {
+    float *acc = reinterpret_cast<float *>(a.accum + pslot);
+    // integer-valued floats: every partial sum is exact, so the order of the atomics does not matter
+    atomicAdd(acc + 0, (float)cr);
+    atomicAdd(acc + 1, (float)cg);
+    atomicAdd(acc + 2, (float)cb);
+    atomicAdd(acc + 3, 1.0f);
+  }
+  if (a.contrib_out) {
+    uint32_t *q = a.contrib_out + ((size_t)gy * (size_t)a.launch_w + gx) * 4;
+    q[0] = cr; q[1] = cg; q[2] = cb; q[3] = 1u;
+  }
+}
+
+template <bool USE_GRAD, int MODE>
+__global__ __launch_bounds__(256) void k_bounce(const RenderArgs a) {
+  const VolumePacked vol = make_volume(a);
+  const uint32_t total = a.n_hits * (uint32_t)a.n_seeds;
+  const unsigned lane = lane_id();
+
+  // the sample
+  uint32_t gx = 0, gy = 0, pslot = 0;
+  int seed = 0;
+  int64_t entry = -1;
+  f3 hit_origin{0, 0, 0}, hit_direction{0, 0, 0}, normal{0, 0, 0};  // hit_information + its normal
+  // path state; energies and colour carry over from distribution ray 1 into ray 2 (SURVEY "hard parts")
+  Ray ray{{0, 0, 0}, {0, 0, 0}};
+  float atten = 0.0f, r_energy = 0.0f, g_energy = 0.0f, b_energy = 0.0f;
+  uint32_t color = 0u, bv_r = 0u, bv_g = 0u, bv_b = 0u;
+  int o = 0, i = 0;
+  // scheduling state
+  int st = ST_IDLE;
+  int ev = EV_NONE;        // pending event of an EVENT lane
+  int sd = 0;              // SDF value for the next step of a MARCH lane
+  int steps_left = 0;
+  bool exhausted = false;  // wave-uniform: the queue has no more items
+
+  for (;;) {
+    // ---- refill idle lanes from the work queue (ballot + prefix compaction) ----------------------
+    const unsigned long long idle_mask = __ballot(st == ST_IDLE);
+    const int n_idle = __popcll(idle_mask);
+    if (!exhausted && n_idle > 0 && (n_idle >= kRefillMinLanes || __ballot(st == ST_MARCH) == 0ull)) {
+      uint32_t base = 0u;
+      const int leader = __ffsll((long long)idle_mask) - 1;
+      if ((int)lane == leader) base = atomicAdd(&a.counters[1], (uint32_t)n_idle);
+      base = __shfl(base, leader);
+      if (base + (uint32_t)n_idle >= total) exhausted = true;
+      if (st == ST_IDLE) {
+        const uint32_t idx = base + prefix_count(idle_mask);
+        if (idx < total) {
+          const uint32_t s = idx / a.n_hits, h = idx - s * a.n_hits;
+          const uint4 *src = reinterpret_cast<const uint4 *>(&a.hits[h]);
+          const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+          hit_origin = f3{__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
+          hit_direction = f3{__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
+          normal = f3{__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)};
+          color = q2.y;
+          entry = (int64_t)(((uint64_t)q2.w << 32) | (uint64_t)q2.z);
+          gx = q3.x & 0xFFFFu;
+          gy = q3.x >> 16;
+          pslot = q3.y;
+          seed = a.seeds[s];
+          bool granted = true;
+          if (MODE == CLWH_ACCUM_VOXEL_CACHE) granted = entry >= 0 && cache_take_token(a.cache, entry, 256u);
+          if (granted) {
+            r_energy = (float)(color & 255u) / 255.0f;
+            g_energy = (float)((color >> 8) & 255u) / 255.0f;
+            b_energy = (float)((color >> 16) & 255u) / 255.0f;
+            bv_r = bv_g = bv_b = 0u;
+            o = 1;
+            st = ST_EVENT;
+            ev = EV_START;
+          } else if (a.contrib_out) {
+            uint32_t *q = a.contrib_out + ((size_t)gy * (size_t)a.launch_w + gx) * 4;
+            q[0] = 0u; q[1] = 0u; q[2] = 0u; q[3] = 0u;
+          }
+        }
+      }
+    }
+    if (__ballot(st != ST_IDLE) == 0ull) {
+      if (exhausted) break;  // nothing in flight and nothing left to fetch
+      continue;              // every fetched item was refused its token: fetch again
+    }
+
+    // ---- step phase: MARCH lanes step until fewer than kStepPhaseMinLanes are still marching -----
+    if (__ballot(st == ST_MARCH) != 0ull) {
+      do {
+        if (st == ST_MARCH) {
+          const float step_size = cl_max((float)sd, 0.5f);
+          ray.origin = ray.origin + ray.direction * step_size;
+          --steps_left;
+          if (exited_volume(vol, ray.origin)) {
+            ev = EV_EXIT;
+            st = ST_EVENT;
+          } else {
+            const uint32_t r = vol.fetch_f(ray.origin.x, ray.origin.y, ray.origin.z);
+            bool is_hit;
+            if (USE_GRAD) {
+              const int gradient = (int)(short)f2i(length3(gradient_nn(vol, ray.origin)));
+              is_hit = tf_eval(a.tf, VolumePacked::value_of(r), gradient, color);
+            } else {
+              const unsigned cls = VolumePacked::class_of(r);
+              is_hit = cls != 0u;
+              if (is_hit) {
+                const TfRuleDev &rule = a.tf.rules[cls - 1u];
+                if (rule.flags & TF_WRITES_COLOR) color = rule.color;
+              }
+            }
+            if (is_hit) {
+              ev = EV_HIT;
+              st = ST_EVENT;
+            } else if (steps_left == 0) {
+              ev = EV_NONE;
+              st = ST_EVENT;
+            } else {
+              sd = VolumePacked::sdf_of(r);
+            }
+          }
+        }
+      } while (__popcll(__ballot(st == ST_MARCH)) >= kStepPhaseMinLanes);
+    }
+
+    // ---- event phase: every parked lane handles its event; the bounce is one shared block ---------
+    if (st == ST_EVENT) {
+      bool start_path = (ev == EV_START);  // begin distribution ray `o` from the primary hit
+      bool bounce = false, from_hit = false;
+      f3 bn = normal;
+      Ray bbase{hit_origin, hit_direction};
+      int bseed = 0;
+
+      if (ev == EV_EXIT) {
+        // ray_marching.cl:54-62: left the volume -> environment light ends this distribution ray
+        const float factor = 8.0f / (float)i;
+        const uint32_t light = sample_environment_map(a.env, a.env_w, a.env_h, ray.direction);
+        // uint += float: promote, add, truncate back
+        bv_r = f2u((float)bv_r + atten * r_energy * (float)(light & 255u) * factor / 1.0f);
+        bv_g = f2u((float)bv_g + atten * g_energy * (float)((light >> 8) & 255u) * factor / 1.0f);
+        bv_b = f2u((float)bv_b + atten * b_energy * (float)((light >> 16) & 255u) * factor / 1.0f);
+        o += 1;
+        start_path = true;
+      } else if (ev == EV_HIT) {
+        // ray_marching.cl:63-72: secondary hit -> bounce around the local normal, attenuate
+        bn = -normalize3(gradient_nn(vol, ray.origin));
+        bbase = ray;
+        bseed = seed + o + i;
+        bounce = true;
+        from_hit = true;
+        i += 1;
+        if (i > 10) {
+          // third march of this distribution ray: the reference still multiplies the energies (they
+          // carry into the next distribution ray) but its bounced ray is never marched
+          r_energy *= (float)(color & 255u) / 255.0f;
+          g_energy *= (float)((color >> 8) & 255u) / 255.0f;
+          b_energy *= (float)((color >> 16) & 255u) / 255.0f;
+          bounce = false;
+          o += 1;
+          start_path = true;
+        }
+      } else if (ev == EV_NONE) {
+        // 70 steps without an event: the next march continues from where this one stopped
+        i += 1;
+        if (i > 10) {
+          o += 1;
+          start_path = true;
+        }
+      }
+
+      if (start_path) {
+        if (o > 2) {
+          finish_item<MODE>(a, entry, pslot, gx, gy, bv_r, bv_g, bv_b);
+          st = ST_IDLE;
+        } else {
+          // ray_marching.cl:48: bounce from the primary hit around the primary normal
+          bn = normal;
+          bbase = Ray{hit_origin, hit_direction};
+          bseed = seed + o;
+          bounce = true;
+          from_hit = false;
+        }
+      }
+
+      if (bounce) {
+        // ray_bounce_fake_reflectance, then origin += normal*2 (ray_marching.cl:48-50 / :65-67)
+        const float roughness = (float)(color >> 24) / 255.0f;
+        Ray nr;
+        nr.origin = bbase.origin + bbase.direction;
+        nr.direction = hemisphere_reflective(gx, gy, bn, bseed, roughness);
+        nr.origin = nr.origin + bn * 2.0f;
+        const float d = fabsf(dot3(nr.direction, bn));
+        if (from_hit) {
+          atten *= d;
+          r_energy *= (float)(color & 255u) / 255.0f;
+          g_energy *= (float)((color >> 8) & 255u) / 255.0f;
+          b_energy *= (float)((color >> 16) & 255u) / 255.0f;
+        } else {
+          atten = d;
+          i = 8;
+        }
+        ray = nr;
+      }
+
+      if (st == ST_EVENT) {
+        // start (or continue) a march: its first SDF read is at trunc(origin) (utility_ray.cl:148-150)
+        sd = vol.sdf_at(f2i(ray.origin.x), f2i(ray.origin.y), f2i(ray.origin.z));
+        steps_left = 70;
+        st = ST_MARCH;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// resolve: every pixel of this rank reads its accumulator after the whole pass (ray_marching.cl:82-99)
+__global__ __launch_bounds__(64) void k_resolve(const RenderArgs a) {
+  const uint32_t slot = blockIdx.x;
+  int tx, ty;
+  if (!tile_from_slot(a, slot, tx, ty)) return;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t x = (uint32_t)tx * 8u + (lane & 7u);
+  const uint32_t y = (uint32_t)ty * 8u + (lane >> 3);
+  if (x >= (uint32_t)a.frame_w || y >= (uint32_t)a.frame_h) return;
+  const uint32_t pslot = slot * 64u + lane;
+  const uint32_t ps = a.pix_slot[pslot];
+  uint32_t out;
+  if (!(ps & PIX_HIT)) {
+    out = (ps & 0x00FFFFFFu) | (200u << 24);  // miss: environment colour, alpha 200
+  } else if (a.mode == CLWH_ACCUM_VOXEL_CACHE) {
+    const HitRec &h = a.hits[ps & ~PIX_HIT];
+    const int64_t e = (int64_t)(((uint64_t)(uint32_t)h.entry_hi << 32) | (uint64_t)(uint32_t)h.entry_lo);
+    if (e < 0) {
+      out = 1u << 24;
+    } else {
+      const uint2 w = *reinterpret_cast<const uint2 *>(a.cache + e * 2);
+      out = tone_map_rgba8(w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16);
+    }
+  } else {
+    const float4 acc = a.accum[pslot];
+    out = tone_map_rgba8((uint32_t)acc.x, (uint32_t)acc.y, (uint32_t)acc.z, (uint32_t)acc.w);
+  }
+  a.frame[(size_t)y * a.frame_w + x] = out;
+}
+
+// gathered image-space accumulation (all ranks' tile-major buffers back to back) -> RGBA8 frame
+__global__ __launch_bounds__(64) void k_accum_resolve(const RenderArgs a, const float4 *__restrict__ accum_all) {
+  const int tx = (int)(blockIdx.x % (unsigned)a.tiles_x), ty = (int)(blockIdx.x / (unsigned)a.tiles_x);
+  const int owner = (tx + ty) % a.tile_world;
+  const size_t slot = (size_t)ty * a.tiles_per_row + (size_t)(tx / a.tile_world);
+  const size_t per_rank = (size_t)a.tiles_y * a.tiles_per_row * 64u;
+  const uint32_t lane = threadIdx.x;
+  const float4 acc = accum_all[(size_t)owner * per_rank + slot * 64u + lane];
+  const uint32_t x = (uint32_t)tx * 8u + (lane & 7u), y = (uint32_t)ty * 8u + (lane >> 3);
+  if (x >= (uint32_t)a.frame_w || y >= (uint32_t)a.frame_h) return;
+  uint32_t out;
+  if (acc.w == 0.0f) {
+    const f3 cam_o = f3{a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]};
+    const f3 cam_d = f3{a.cam_dir[0], a.cam_dir[1], a.cam_dir[2]};
+    const Ray vray = generate_ray(cam_o, cam_d, (int)x, (int)y, a.frame_w, a.frame_h);
+    const uint32_t e = sample_environment_map(a.env, a.env_w, a.env_h, vray.direction);
+    out = (e & 0x00FFFFFFu) | (200u << 24);
+  } else {
+    out = tone_map_rgba8((uint32_t)acc.x, (uint32_t)acc.y, (uint32_t)acc.z, (uint32_t)acc.w);
+  }
+  a.frame[(size_t)y * a.frame_w + x] = out;
+}
+
+// ------------------------------------------------------------------------------------------------
 hipError_t launch_repack(const RepackArgs &a, hipStream_t s) {
   const size_t n_sub = (size_t)a.NBX * a.NBY * a.NBZ * 8u;
   hipLaunchKernelGGL(k_repack, dim3((unsigned)((n_sub + 3u) / 4u)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
-hipError_t launch_render_v0(const RenderArgs &a, hipStream_t s) {
-  if (a.packed) {
-    if (a.tf.uses_gradient)
-      hipLaunchKernelGGL((k_render_v0<true, VolumePacked>), dim3(a.num_blocks), dim3(64), 0, s, a);
-    else
-      hipLaunchKernelGGL((k_render_v0<false, VolumePacked>), dim3(a.num_blocks), dim3(64), 0, s, a);
+hipError_t launch_primary(const RenderArgs &a, hipStream_t s) {
+  if (a.tf.uses_gradient)
+    hipLaunchKernelGGL(k_primary<true>, dim3(a.num_tile_slots), dim3(64), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_primary<false>, dim3(a.num_tile_slots), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_bounce(const RenderArgs &a, hipStream_t s) {
+  const uint64_t total = (uint64_t)a.n_hits * (uint64_t)a.n_seeds;
+  if (total == 0) return hipSuccess;
+  // persistent grid: enough waves to fill the chip (256 CUs x 32 waves), never more than the work
+  const uint64_t waves_needed = (total + 63u) / 64u;
+  const unsigned blocks = (unsigned)std::min<uint64_t>((waves_needed + 3u) / 4u, 2048u);
+  const dim3 grid(blocks), block(256);
+  const bool g = a.tf.uses_gradient != 0;
+  if (a.mode == CLWH_ACCUM_VOXEL_CACHE) {
+    if (g) hipLaunchKernelGGL((k_bounce<true, CLWH_ACCUM_VOXEL_CACHE>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_bounce<false, CLWH_ACCUM_VOXEL_CACHE>), grid, block, 0, s, a);
   } else {
-    if (a.tf.uses_gradient)
-      hipLaunchKernelGGL((k_render_v0<true, VolumeLinear>), dim3(a.num_blocks), dim3(64), 0, s, a);
-    else
-      hipLaunchKernelGGL((k_render_v0<false, VolumeLinear>), dim3(a.num_blocks), dim3(64), 0, s, a);
+    if (g) hipLaunchKernelGGL((k_bounce<true, CLWH_ACCUM_IMAGE_SPACE>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((k_bounce<false, CLWH_ACCUM_IMAGE_SPACE>), grid, block, 0, s, a);
   }
   return hipGetLastError();
 }
 
 hipError_t launch_resolve(const RenderArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL(k_resolve, dim3(a.num_blocks), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_resolve, dim3(a.num_tile_slots), dim3(64), 0, s, a);
   return hipGetLastError();
 }
 
-hipError_t launch_accum_resolve(const float4 *accum_all, int32_t tile_world, int32_t width, int32_t height,
-                                uint32_t *frame, int32_t frame_w, int32_t frame_h, hipStream_t s) {
-  const int tiles_x = width / 8, tiles_y = height / 8;
-  const int tiles_per_row = (tiles_x + tile_world - 1) / tile_world;
-  hipLaunchKernelGGL(k_accum_resolve, dim3((uint32_t)(tiles_x * tiles_y)), dim3(64), 0, s, accum_all, tile_world,
-                     tiles_x, tiles_y, tiles_per_row, frame, frame_w, frame_h);
+hipError_t launch_accum_resolve(const RenderArgs &a, const float4 *accum_all, hipStream_t s) {
+  hipLaunchKernelGGL(k_accum_resolve, dim3((uint32_t)(a.tiles_x * a.tiles_y)), dim3(64), 0, s, a, accum_all);
   return hipGetLastError();
 }
 

@@ -65,6 +65,7 @@ class RenderDesc(C.Structure):
         ("tile_rank", C.c_int32), ("tile_world", C.c_int32),
         ("write_frame", C.c_int32),
         ("hit_index", C.c_void_p), ("contrib", C.c_void_p),
+        ("n_seeds", C.c_int32), ("seeds", C.c_int32 * 16),
     ]
 
 
@@ -93,7 +94,9 @@ _PROTOTYPES = [
     ("clwh_render", C.c_int, [C.c_void_p, C.POINTER(RenderDesc)]),
     ("clwh_cache_len", C.c_int64, [C.c_uint32, C.c_uint32, C.c_uint32]),
     ("clwh_accum_len", C.c_int64, [C.c_uint32, C.c_uint32, C.c_int32]),
-    ("clwh_accum_resolve", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    ("clwh_accum_resolve", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                     C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("clwh_ctx_invalidate_derived", C.c_int, [C.c_void_p]),
     ("clwh_sdf_build", C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int32)]),
     ("clwh_buffer_reset", C.c_int, [C.c_void_p, C.c_void_p]),
     ("clwh_tf_parse", C.c_int, [C.c_char_p, C.POINTER(Tf)]),
@@ -191,7 +194,7 @@ class Kernel:
 
     def render(self, *, frame, volume, sdf, env, cam_pos, cam_dir, seed, width, height, buffer_volume=None,
                accum=None, mode=ACCUM_VOXEL_CACHE, tile_rank=0, tile_world=1, write_frame=True,
-               hit_index=None, contrib=None):
+               hit_index=None, contrib=None, seeds=None):
         d = RenderDesc()
         d.frame = frame.h if frame is not None else None
         d.volume, d.sdf, d.env = volume.h, sdf.h, env.h
@@ -206,6 +209,10 @@ class Kernel:
         d.write_frame = 1 if write_frame else 0
         d.hit_index = hit_index.h if hit_index is not None else None
         d.contrib = contrib.h if contrib is not None else None
+        if seeds is not None:
+            d.n_seeds = len(seeds)
+            for i, sd in enumerate(seeds):
+                d.seeds[i] = int(sd)
         _check(lib().clwh_render(self.h, C.byref(d)), "clwh_render")
 
     def release(self):
@@ -275,9 +282,14 @@ class Context:
     def buffer_reset(self, buffer_volume: Mem):
         _check(lib().clwh_buffer_reset(self.h, buffer_volume.h), "clwh_buffer_reset")
 
-    def accum_resolve(self, accum_all: Mem, tile_world, width, height, frame: Mem):
-        _check(lib().clwh_accum_resolve(self.h, accum_all.h, tile_world, width, height, frame.h),
+    def accum_resolve(self, accum_all: Mem, tile_world, width, height, frame: Mem, env: Mem, cam_pos, cam_dir):
+        p = (C.c_float * 3)(*[float(x) for x in cam_pos])
+        d = (C.c_float * 3)(*[float(x) for x in cam_dir])
+        _check(lib().clwh_accum_resolve(self.h, accum_all.h, tile_world, width, height, frame.h, env.h, p, d),
                "clwh_accum_resolve")
+
+    def invalidate_derived(self):
+        _check(lib().clwh_ctx_invalidate_derived(self.h), "clwh_ctx_invalidate_derived")
 
     def finish(self):
         _check(lib().clwh_ctx_finish(self.h), "clwh_ctx_finish")

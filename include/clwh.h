@@ -137,15 +137,20 @@ typedef struct clwh_render_desc {
   clwh_mem *buffer_volume;  /* voxel cache, clwh_cache_len() ushorts (mode 0) */
   float cam_pos[3];
   float cam_dir[3];
-  int32_t seed;
+  int32_t seed;             /* the pass's random seed (renderer.cpp:142) when n_seeds == 0 */
   uint32_t width, height;   /* NDRange global size (multiples of 8) */
   int32_t accum_mode;
   clwh_mem *accum;          /* mode 1: float4 per pixel, tile-major (see clwh_accum_len) */
   int32_t tile_rank, tile_world; /* image-tile partition: 8x8 tiles, owner = (tx + ty) % world */
   int32_t write_frame;      /* 1: resolve the frame (deterministic, after all adds of the pass) */
   clwh_mem *hit_index;      /* optional int64 per pixel, row-major: cache entry or -1 (parity tests) */
-  clwh_mem *contrib;        /* optional uint32[4] per pixel, row-major: r,g,b,granted (parity tests) */
+  clwh_mem *contrib;        /* optional uint32[4] per pixel, row-major: r,g,b,granted (parity tests; one seed) */
+  int32_t n_seeds;          /* > 0: render n_seeds passes (<= CLWH_MAX_SEEDS) in ONE launch, seeds[] below; the
+                               result equals n_seeds consecutive single-seed calls (image-space mode always; voxel
+                               cache mode while no voxel reaches the 256-token cap) */
+  int32_t seeds[16];
 } clwh_render_desc;
+#define CLWH_MAX_SEEDS 16
 int clwh_render(clwh_kernel *render_kernel, const clwh_render_desc *desc);
 
 /* number of ushorts of a voxel cache for an X*Y*Z volume (the reference allocates X*Y*Z*4,
@@ -154,10 +159,17 @@ int clwh_render(clwh_kernel *render_kernel, const clwh_render_desc *desc);
 int64_t clwh_cache_len(uint32_t X, uint32_t Y, uint32_t Z);
 /* number of float4 of a rank's tile-major accumulation buffer */
 int64_t clwh_accum_len(uint32_t width, uint32_t height, int32_t tile_world);
-/* scatter one rank's tile-major accumulation tiles into a row-major float4 frame and resolve the
- * RGBA8 frame from it (ray_marching.cl:82-99 applied per pixel); used after the RCCL gather */
+/* resolve the RGBA8 frame from the tile-major accumulation buffers of all ranks laid back to back
+ * (what the RCCL all-gather produces): hit pixels (count > 0) get ray_marching.cl:82-99 applied to
+ * their sums; the others get the environment colour of their camera ray, alpha 200
+ * (ray_marching.cl:172-178), which is why the camera and the env map are arguments. */
 int clwh_accum_resolve(clwh_ctx *ctx, clwh_mem *accum_all_ranks, int32_t tile_world, uint32_t width,
-                       uint32_t height, clwh_mem *frame_rgba8);
+                       uint32_t height, clwh_mem *frame_rgba8, clwh_mem *env, const float cam_pos[3],
+                       const float cam_dir[3]);
+/* drop everything the context derived from its inputs (packed records, per-camera primary hits);
+ * the next clwh_render rebuilds them.  Needed only when device memory was rewritten behind the
+ * shim's back, or to time the rebuild. */
+int clwh_ctx_invalidate_derived(clwh_ctx *ctx);
 
 /* clwh_sdf_build replaces the host loop of signed_distance_field::signed_distance_field
  * (app/signed_distance_field.cpp:7-35): base image + all propagation layers, no host round trip

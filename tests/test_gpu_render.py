@@ -145,54 +145,94 @@ def test_image_space_mode_and_tile_partition(gpu_ctx, orc):
     for s in seeds:
         o.render(pos, d, s)
         one.render(pos, d, s, mode=ffi.ACCUM_IMAGE_SPACE)
+        assert np.array_equal(one.contrib.pull(), o.contrib)
     o.resolve(pos, d)
     got = one.accum_row_major(0)
     hit = o.hit_index.reshape(h, w) >= 0
     assert np.array_equal(got[hit], o.accum[hit])
-    assert np.all(got[~hit][:, 3] == 0)
+    assert not got[~hit].any()  # misses never touch the accumulation buffer
     assert np.array_equal(one.frame.pull(), o.frame)
 
     for world in (2, 3):
         many = GpuScene(gpu_ctx, vol, sdf, env, tf, (w, h), world=world)
         for r in range(world):
             for s in seeds:
-                many.render(pos, d, s, mode=ffi.ACCUM_IMAGE_SPACE, rank=r, write_frame=False)
+                many.render(pos, d, s, mode=ffi.ACCUM_IMAGE_SPACE, rank=r, write_frame=False, debug=False)
         merged = sum(many.accum_row_major(r) for r in range(world))
         assert np.array_equal(merged, got)
         # what the RCCL all-gather produces: the ranks' buffers back to back -> one resolve
         allr = np.concatenate([many.accum[r].pull(np.float32) for r in range(world)])
         buf = gpu_ctx.buffer_from(allr)
-        gpu_ctx.accum_resolve(buf, world, w, h, many.frame)
+        many.frame.push(np.zeros((h, w, 4), np.uint8))
+        gpu_ctx.accum_resolve(buf, world, w, h, many.frame, many.env, pos, d)
         assert np.array_equal(many.frame.pull(), o.frame)
         buf.release()
         many.release()
     one.release()
 
 
-def test_linear_layout_path_agrees_with_packed_records(orc):
-    """CLWH_RENDER_PATH=linear keeps the caller's x-fastest images (the A/B arm of the layout
-    measurement in DESIGN.md); both arms must produce the same bits."""
-    import os
-
-    vol, sdf, env, tf = small_scene(orc, 48, dims=(50, 44, 37))
+@pytest.mark.parametrize("mode", ["voxel", "image"])
+def test_several_seeds_in_one_launch(gpu_ctx, orc, mode):
+    """n_seeds passes fused into one launch of the persistent bounce kernel == the same passes one by one."""
+    vol, sdf, env, tf = small_scene(orc, 48)
     pos, d = look_at_centre(vol, [-20, 40, -20])
-    out = {}
-    for arm in ("linear", "packed"):
-        if arm == "linear":
-            os.environ["CLWH_RENDER_PATH"] = "linear"
-        else:
-            os.environ.pop("CLWH_RENDER_PATH", None)
-        ctx = ffi.Context(0)
-        g = GpuScene(ctx, vol, sdf, env, tf, (128, 128))
-        for s in scene.glibc_rand(3):
-            g.render(pos, d, s)
-        out[arm] = (g.cache.pull(), g.frame.pull())
-        g.release()
-        ctx.destroy()
-    os.environ.pop("CLWH_RENDER_PATH", None)
-    assert np.array_equal(out["linear"][0], out["packed"][0])
-    assert np.array_equal(out["linear"][1], out["packed"][1])
-    o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (128, 128))
-    for s in scene.glibc_rand(3):
+    w, h = 160, 96
+    seeds = scene.glibc_rand(7)
+    omode = orc.MODE_VOXEL_CACHE if mode == "voxel" else orc.MODE_IMAGE_SPACE
+    gmode = ffi.ACCUM_VOXEL_CACHE if mode == "voxel" else ffi.ACCUM_IMAGE_SPACE
+    o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (w, h), mode=omode)
+    for s in seeds:
         o.render(pos, d, s)
-    assert np.array_equal(out["packed"][0], o.cache)
+    o.resolve(pos, d)
+    g = GpuScene(gpu_ctx, vol, sdf, env, tf, (w, h))
+    g.render(pos, d, None, mode=gmode, seeds=seeds[:4], debug=False)
+    g.render(pos, d, None, mode=gmode, seeds=seeds[4:], debug=False)
+    if mode == "voxel":
+        assert o.cache.reshape(-1, 4)[:, 3].max() < 256
+        assert np.array_equal(g.cache.pull(), o.cache)
+    else:
+        hit = o.hit_index.reshape(h, w) >= 0
+        assert np.array_equal(g.accum_row_major(0)[hit], o.accum[hit])
+    assert np.array_equal(g.frame.pull(), o.frame)
+    g.release()
+
+
+def test_primary_hits_follow_camera_volume_and_tf_changes(gpu_ctx, orc):
+    """the per-camera primary hits and the packed records are derived data: every input change must
+    rebuild them (camera move, TF flush, SDF rebuild, volume push)."""
+    vol, sdf, env, tf = small_scene(orc, 40)
+    w, h = 96, 96
+    g = GpuScene(gpu_ctx, vol, sdf, env, tf, (w, h))
+    o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (w, h))
+    cams = [look_at_centre(vol, [-20, 40, -20]), look_at_centre(vol, [60, 10, -30]), look_at_centre(vol, [-20, 40, -20])]
+    for k, (pos, d) in enumerate(cams):
+        for s in (100 + k, 200 + k):
+            g.render(pos, d, s, debug=False)
+            o.render(pos, d, s)
+    assert np.array_equal(g.cache.pull(), o.cache)
+    # TF flush: new kernel object with another TF, new SDF pushed into the same image, cache reset
+    tf2 = scene.tf_rect_source([(20.0, 60.0, 0.0, 4000.0, (0.9, 0.5, 0.2, 0.6))])
+    sdf2, _, _ = orc.sdf_build(vol, orc.parse_tf(tf2))
+    g.sdf.push(sdf2)
+    g.kernel.release()
+    g.kernel = gpu_ctx.kernel("ray_marching.cl", "render", tf2)
+    gpu_ctx.buffer_reset(g.cache)
+    o2 = orc.Scene(vol, sdf2, env, orc.parse_tf(tf2), (w, h))
+    pos, d = cams[0]
+    for s in (7, 8):
+        g.render(pos, d, s, debug=False)
+        o2.render(pos, d, s)
+    assert np.array_equal(g.cache.pull(), o2.cache)
+    # volume push (same shape, other content)
+    vol3 = np.ascontiguousarray(vol[::-1])
+    sdf3, _, _ = orc.sdf_build(vol3, orc.parse_tf(tf2))
+    g.volume.push(vol3)
+    g.sdf.push(sdf3)
+    gpu_ctx.buffer_reset(g.cache)
+    o3 = orc.Scene(vol3, sdf3, env, orc.parse_tf(tf2), (w, h))
+    g.render(pos, d, 9, debug=False)
+    o3.render(pos, d, 9)
+    o3.resolve(pos, d)
+    assert np.array_equal(g.cache.pull(), o3.cache)
+    assert np.array_equal(g.frame.pull(), o3.frame)
+    g.release()
