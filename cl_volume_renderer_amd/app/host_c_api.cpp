@@ -1,0 +1,80 @@
+// host_c_api.cpp -- a small extern "C" facade over the C++ host mirror (renderer, reference_volume,
+// env_map, signed_distance_field) so that pytest can drive the very call sequence the SDL/ImGui
+// application performs (reference app/ui.cpp:170-199, 296) without SDL.  Test / tooling entry points;
+// the product ABI is include/clwh.h.
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "renderer.hpp"
+
+struct clvr_host {
+  clw_context ctx;
+  renderer rend;
+  std::unique_ptr<volume_block> block;
+  std::unique_ptr<reference_volume> rv;
+  std::unique_ptr<env_map> emap;
+  ui_state state;
+  clvr_host() : rend(ctx), state{"", true, 0, 0, Position3D(0, 0, 0), {0.f, 0.f}, true} {}
+};
+
+extern "C" {
+
+clvr_host *clvr_host_create(void) { return new clvr_host(); }
+void clvr_host_destroy(clvr_host *h) { delete h; }
+
+// nrrd_loader::load_file + reference_volume + hdre_loader + env_map + image_set  (ui.cpp:182-194)
+void clvr_host_load(clvr_host *h, const short *voxels, unsigned X, unsigned Y, unsigned Z, const unsigned char *env_rgba,
+                    unsigned env_w, unsigned env_h) {
+  h->block.reset(new volume_block(std::vector<short>(voxels, voxels + (size_t)X * Y * Z), X, Y, Z, 1.f, 1.f, 1.f));
+  h->rv.reset(new reference_volume(h->ctx, h->block.get()));
+  h->rv->set_value_clip({-2000, 3000});
+  h->rv->set_gradient_clip({0, 4000});
+  image em;
+  em.m_pixels.assign(env_rgba, env_rgba + (size_t)env_w * env_h * 4);
+  em.m_width = env_w;
+  em.m_height = env_h;
+  h->emap.reset(new env_map(h->ctx, em));
+  h->rend.image_set(h->rv.get(), h->emap.get());
+}
+
+// flush_tf + flush_changes  (ui.cpp:195-197)
+void clvr_host_flush(clvr_host *h, const char *cl_code) {
+  h->rend.next_event_code_set(cl_code);
+  h->rend.flush_changes();
+}
+
+// one iteration of the ui::run loop body that matters here (ui.cpp:296)
+const void *clvr_host_render_frame(clvr_host *h, const float pos[3], const float look[2], int width, int height,
+                                   int cam_changed, int *frame_changed) {
+  h->state.position = Position3D(pos[0], pos[1], pos[2]);
+  h->state.direction_look[0] = look[0];
+  h->state.direction_look[1] = look[1];
+  h->state.width = width;
+  h->state.height = height;
+  h->state.cam_changed = cam_changed != 0;
+  bool changed = false;
+  void *p = h->rend.render_frame(h->state, changed);
+  if (frame_changed) *frame_changed = changed ? 1 : 0;
+  return p;
+}
+
+size_t clvr_host_cache_len(clvr_host *h) { return h->rend.voxel_cache().size(); }
+void clvr_host_pull_cache(clvr_host *h, unsigned short *out) {
+  auto &c = h->rend.voxel_cache();
+  c.pull();
+  std::memcpy(out, &c[0], c.size() * sizeof(unsigned short));
+}
+size_t clvr_host_sdf_len(clvr_host *h) { return h->rend.distance_field().get_sdf_buffer().size(); }
+void clvr_host_pull_sdf(clvr_host *h, signed char *out) {
+  auto &s = h->rend.distance_field().get_sdf_buffer();
+  s.pull();
+  std::memcpy(out, &s[0], s.size());
+}
+int clvr_host_sdf_layers(clvr_host *h) { return h->rend.distance_field().layers(); }
+void clvr_host_camera_direction(float alpha, float beta, float out[3]) {
+  Position3D v(alpha, beta, 0.0, {1.0, 0.0, 0.0});
+  out[0] = v.val[0]; out[1] = v.val[1]; out[2] = v.val[2];
+}
+
+}  // extern "C"

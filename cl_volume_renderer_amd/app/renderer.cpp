@@ -1,0 +1,70 @@
+#include "renderer.hpp"
+
+#include <cstdlib>
+
+#include <clwh.h>
+
+#include "common_defines.hpp"
+
+// Mirrors the sequencing of the reference's app/renderer.cpp; what differs is below the clw_* API:
+// no JIT on flush, the SDF build is one call, and the frame the caller receives is resolved after the
+// pass instead of being read from the cache while other work-items still add to it.
+
+renderer::renderer(clw_context &c)
+    : ctx(c),
+      render_func(ctx, "empty.cl", "empty"),
+      frame(ctx, std::vector<unsigned char>((size_t)SCREEN_WIDTH * SCREEN_HEIGHT * 4), {SCREEN_WIDTH, SCREEN_HEIGHT, 1}),
+      buffer_volume(ctx, std::vector<unsigned short>(8 * 4)),
+      tfframe(ctx, std::vector<unsigned char>(2 * 2 * 4), {2, 2, 1}),
+      sdf(ctx) {}
+
+void renderer::image_set(const reference_volume *rv, const env_map *map) {
+  volume = rv;
+  emap = map;
+}
+
+void renderer::next_event_code_set(const std::string cl_code) { local_cl_code = cl_code; }
+
+// reference :25-43 -- (re)allocate + zero the voxel cache, rebuild the render function and the SDF
+void renderer::flush_changes() {
+  const auto dims = volume->get_volume_size();
+  // the reference allocates X*Y*Z*4 ushorts and can index one row past it (opencl_kernels/utility.cl:21
+  // with utility_ray.cl:112-117); the padded length keeps that access inside the buffer
+  const size_t cache_len = (size_t)clwh_cache_len((uint32_t)dims[0], (uint32_t)dims[1], (uint32_t)dims[2]);
+  if (buffer_volume.size() != cache_len)
+    buffer_volume = clw_vector<unsigned short>(ctx, std::vector<unsigned short>(cache_len), false);
+
+  auto buffer_reset = clw_function(ctx, "buffer_reset.cl", "buffer_reset");
+  buffer_reset.execute(volume->get_volume_size_evenness(4), {4, 4, 4}, volume->get_reference_volume(), buffer_volume);
+
+  render_func = clw_function(ctx, "ray_marching.cl", "render", local_cl_code);
+  sdf = signed_distance_field(ctx, *volume, local_cl_code);
+}
+
+// reference :131-158 -- one sample per pixel with a fresh std::rand() seed, then a blocking readback
+void *renderer::render_frame(struct ui_state &state, bool &frame_changed) {
+  frame_changed = false;
+  if (!state.cam_changed && !state.path_changed) return &frame[0];
+
+  Position3D vec(state.direction_look[0], state.direction_look[1], 0.0, {1.0, 0.0, 0.0});
+  const int random_seed = std::rand();
+
+  render_func.execute({(size_t)state.width, (size_t)state.height, 1}, {8, 8, 1}, frame, volume->get_reference_volume(),
+                      sdf.get_sdf_buffer(), emap->get_buffer(), buffer_volume, state.position.val[0],
+                      state.position.val[1], state.position.val[2], vec.val[0], vec.val[1], vec.val[2], random_seed);
+  frame.pull();
+
+  state.cam_changed = false;
+  state.path_changed = false;
+  frame_changed = true;
+  return &frame[0];
+}
+
+// The 2-D (value, gradient) histogram texture of the transfer-function editor (reference :45-124) is a
+// UI widget outside the hot path; the symbol is kept so the application
+// links, and returns a transparent image of the requested size.
+void *renderer::render_tf(const unsigned int height, const unsigned int width) {
+  const unsigned int w = width < 2 ? 2 : width, h = height < 1 ? 1 : height;
+  tfframe = clw_image<unsigned char, 4>(ctx, std::vector<unsigned char>((size_t)w * h * 4, 0), {w, h, 1});
+  return &tfframe[0];
+}

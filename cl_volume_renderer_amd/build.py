@@ -25,6 +25,28 @@ FLAGS = [
 ]
 
 
+HOST_LIB = os.path.join(HERE, "libclvr_host.so")
+APP = os.path.join(HERE, "app")
+HOST_SOURCES = ["renderer.cpp", "reference_volume.cpp", "signed_distance_field.cpp", "host_c_api.cpp"]
+CXX = os.environ.get("CXX", "g++")
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """The C++ host mirror of the reference's renderer / reference_volume / signed_distance_field,
+    compiled with plain g++ against include/clw_*.hpp and linked to libclwhip.so."""
+    deps = [os.path.join(APP, f) for f in os.listdir(APP)]
+    deps += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))] + [LIB]
+    if not force and os.path.exists(HOST_LIB) and all(os.path.getmtime(d) <= os.path.getmtime(HOST_LIB) for d in deps):
+        return HOST_LIB
+    cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", APP]
+    cmd += [os.path.join(APP, s) for s in HOST_SOURCES]
+    cmd += ["-o", HOST_LIB, "-L", HERE, "-lclwhip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return HOST_LIB
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
@@ -45,3 +67,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_host(force="--force" in sys.argv, verbose=True))
