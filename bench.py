@@ -92,7 +92,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from cl_volume_renderer_amd import ffi, scene
+    from cl_volume_renderer_amd import ffi, scene, tiles
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
@@ -159,10 +159,7 @@ def main():
     t0 = time.perf_counter()
     for b in batches(seeds[args.warmup:]):
         render_passes(b)
-    if world > 1:
-        dist.all_gather_into_tensor(accum_all, accum)  # RCCL over xGMI: float4 tiles of every rank
-    else:
-        accum_all.copy_(accum)
+    tiles.gather_accum(accum, accum_all, world)  # N>1: ONE RCCL all-gather of the float4 tiles over xGMI
     ctx.accum_resolve(m_accum_all, world, W, H, d_frame, d_env, pos, cdir)
     torch.cuda.synchronize()
     barrier()

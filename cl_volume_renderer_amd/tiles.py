@@ -1,0 +1,63 @@
+"""Image-tile partition of a frame over ranks and the one collective of the path.
+
+8x8 pixel tiles, owner = (tx + ty) % world; a rank numbers its tiles
+``slot = ty * tiles_per_row + tx // world`` and stores 64 float4 per slot (tile-major), which is the
+layout the HIP kernels write (csrc/render_device.hpp ``tile_from_slot``) and ``clwh_accum_resolve`` reads.
+The gather works on any torch device/backend (RCCL on the GPUs, gloo in the CPU tests).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def tiles_per_row(width: int, world: int) -> int:
+    return (width // 8 + world - 1) // world
+
+
+def accum_len(width: int, height: int, world: int) -> int:
+    """float4 elements of one rank's buffer (== clwh_accum_len)."""
+    return (height // 8) * tiles_per_row(width, world) * 64
+
+
+def owner_of_tile(tx: int, ty: int, world: int) -> int:
+    return (tx + ty) % world
+
+
+def pack_tile_major(row_major: np.ndarray, rank: int, world: int) -> np.ndarray:
+    """[h][w][4] -> the rank's tile-major buffer [slots*64][4] (tiles of other ranks are left out)."""
+    h, w, _ = row_major.shape
+    per_row = tiles_per_row(w, world)
+    out = np.zeros(((h // 8) * per_row * 64, 4), dtype=row_major.dtype)
+    for ty in range(h // 8):
+        for tx in range(w // 8):
+            if owner_of_tile(tx, ty, world) != rank:
+                continue
+            slot = ty * per_row + tx // world
+            out[slot * 64:(slot + 1) * 64] = row_major[ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8].reshape(64, 4)
+    return out
+
+
+def unpack_all_ranks(accum_all: np.ndarray, world: int, width: int, height: int) -> np.ndarray:
+    """all ranks' buffers back to back (what the all-gather produces) -> [h][w][4]."""
+    per_row = tiles_per_row(width, world)
+    per_rank = (height // 8) * per_row * 64
+    a = accum_all.reshape(world, per_rank, 4)
+    out = np.zeros((height, width, 4), dtype=accum_all.dtype)
+    for ty in range(height // 8):
+        for tx in range(width // 8):
+            r = owner_of_tile(tx, ty, world)
+            slot = ty * per_row + tx // world
+            out[ty * 8:ty * 8 + 8, tx * 8:tx * 8 + 8] = a[r, slot * 64:(slot + 1) * 64].reshape(8, 8, 4)
+    return out
+
+
+def gather_accum(accum, accum_all, world: int):
+    """The path's only collective: every rank contributes its tile-major float4 buffer, every rank
+    receives all of them back to back.  `accum`, `accum_all`: 1-D torch tensors on the same device."""
+    if world == 1:
+        accum_all.copy_(accum)
+        return accum_all
+    import torch.distributed as dist
+
+    dist.all_gather_into_tensor(accum_all, accum)
+    return accum_all

@@ -1,0 +1,88 @@
+"""N>1 path on CPU: two gloo ranks shard one frame into interleaved 8x8 tiles, each renders its
+tiles (with the oracle standing in for the device kernels), the tile-major float4 buffers are
+all-gathered by the same function bench.py uses, and the unpacked frame equals the single-rank one."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from cl_volume_renderer_amd import scene, tiles
+
+W, H, WORLD = 96, 64, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene(orc_ffi):
+    vol = scene.phantom(32)
+    tf = orc_ffi.parse_tf(scene.tf_default_source())
+    sdf, _, _ = orc_ffi.sdf_build(vol, tf)
+    env = scene.env_map(128, 64)
+    pos = np.array([-14, 28, -14], np.float32)
+    d = np.array([16, 16, 16], np.float32) - pos
+    return vol, sdf, env, tf, pos, (d / np.linalg.norm(d)).astype(np.float32)
+
+
+def _worker(rank, port, out_path):
+    import torch
+    import torch.distributed as dist
+
+    from oracle import orc_ffi
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    vol, sdf, env, tf, pos, d = _scene(orc_ffi)
+    sc = orc_ffi.Scene(vol, sdf, env, tf, (W, H), mode=orc_ffi.MODE_IMAGE_SPACE, tile_rank=rank, tile_world=WORLD)
+    for s in scene.glibc_rand(3):
+        sc.render(pos, d, s)
+    mine = torch.from_numpy(tiles.pack_tile_major(sc.accum, rank, WORLD).reshape(-1).copy())
+    assert mine.numel() == tiles.accum_len(W, H, WORLD) * 4
+    everyone = torch.zeros(mine.numel() * WORLD, dtype=torch.float32)
+    tiles.gather_accum(mine, everyone, WORLD)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)  # the max-over-ranks reduction bench.py applies to its timing
+    assert t.item() == WORLD
+    if rank == 0:
+        np.save(out_path, tiles.unpack_all_ranks(everyone.numpy(), WORLD, W, H))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_tile_partition_and_gather(orc, tmp_path):
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "gathered.npy")
+    mp.spawn(_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+    gathered = np.load(out)
+
+    vol, sdf, env, tf, pos, d = _scene(orc)
+    one = orc.Scene(vol, sdf, env, tf, (W, H), mode=orc.MODE_IMAGE_SPACE)
+    for s in scene.glibc_rand(3):
+        one.render(pos, d, s)
+    assert one.accum[..., 3].max() == 3
+    assert np.array_equal(gathered, one.accum)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_tile_major_round_trip(world):
+    rng = np.random.default_rng(world)
+    w, h = 128, 72
+    full = rng.random((h, w, 4), dtype=np.float32)
+    parts = [tiles.pack_tile_major(full, r, world) for r in range(world)]
+    assert all(p.shape[0] == tiles.accum_len(w, h, world) for p in parts)
+    assert np.array_equal(tiles.unpack_all_ranks(np.concatenate(parts), world, w, h), full)
+
+
+def test_accum_len_matches_the_c_abi():
+    from cl_volume_renderer_amd import ffi
+
+    for (w, h, world) in [(1920, 1080, 1), (1920, 1080, 8), (3840, 2160, 8), (64, 64, 3), (96, 64, 2)]:
+        assert tiles.accum_len(w, h, world) == ffi.accum_len(w, h, world)
