@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-secondary", action="store_true", help="skip the voxel-cache-mode measurement")
-    ap.add_argument("--seeds-per-launch", type=int, default=8,
+    ap.add_argument("--seeds-per-launch", type=int, default=16,
                     help="render passes fused into one launch of the persistent bounce kernel (1..16)")
     args = ap.parse_args()
 

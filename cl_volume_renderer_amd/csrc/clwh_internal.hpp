@@ -44,6 +44,7 @@ enum : uint32_t { PIX_HIT = 0x80000000u };  // pix_slot: PIX_HIT | hit index, el
 struct RenderArgs {
   int32_t X, Y, Z;
   const uint32_t *packed;  // bricked {value, sdf, class} records (packed_volume.hpp)
+  const uint8_t *stepb;    // bricked per-step bytes (packed_volume.hpp)
   int32_t NBX, NBY;
   const uint32_t *env;     // RGBA8 packed, row-major
   int32_t env_w, env_h;
@@ -60,13 +61,19 @@ struct RenderArgs {
   float4 *accum;           // tile-major float4 per pixel slot (mode 1)
   uint32_t *pix_slot;      // tile-major, per pixel: PIX_HIT | hit index, or the miss colour
   HitRec *hits;            // compacted primary hits of this camera
-  uint32_t *counters;      // [0] number of hits (k_primary), [1] work-queue head (k_bounce)
+  uint32_t *counters;      // [0] hits (k_primary), [1] queue head, [2] fix-up records, [3] fix-up overflow flag
+  uint32_t *fixups;        // 128-byte records of samples whose env lookup needs the exact route
+  uint32_t fixup_capacity;
   uint32_t n_hits;         // host copy of counters[0] (valid for k_bounce / k_resolve)
   int64_t *hit_index_out;  // optional, row-major over launch_w x launch_h
   uint32_t *contrib_out;   // optional, row-major uint32[4] (single seed)
   uint32_t num_tile_slots; // tile slots of this rank
   int32_t n_seeds;
   int32_t seeds[CLWH_MAX_SEEDS];
+  // scheduling knobs of k_bounce (defaults in clwh_runtime.hip; CLWH_TUNE_* override for experiments)
+  int32_t step_min_lanes;    // keep stepping while at least this many lanes march
+  int32_t refill_min_lanes;  // refill when at least this many lanes are idle
+  uint32_t bounce_max_blocks;  // persistent grid size (256-thread blocks)
   TfDev tf;
 };
 
@@ -77,6 +84,7 @@ struct RepackArgs {
   int32_t X, Y, Z;
   int32_t NBX, NBY, NBZ;
   uint32_t *packed;
+  uint8_t *stepb;
   TfDev tf;
 };
 
@@ -98,6 +106,7 @@ struct SdfArgs {
 hipError_t launch_repack(const RepackArgs &a, hipStream_t s);
 hipError_t launch_primary(const RenderArgs &a, hipStream_t s);
 hipError_t launch_bounce(const RenderArgs &a, hipStream_t s);
+hipError_t launch_env_fixup(const RenderArgs &a, hipStream_t s);
 hipError_t launch_resolve(const RenderArgs &a, hipStream_t s);
 hipError_t launch_accum_resolve(const RenderArgs &a, const float4 *accum_all, hipStream_t s);
 hipError_t launch_sdf_base(const SdfArgs &a, hipStream_t s);
@@ -115,7 +124,14 @@ struct clwh_ctx {
   size_t pix_slot_bytes = 0;
   clvr::HitRec *hits = nullptr;
   size_t hits_bytes = 0;
-  uint32_t *render_counters = nullptr;  // 2 x u32 on the device
+  uint32_t *render_counters = nullptr;  // 4 x u32 on the device
+  uint32_t *fixups = nullptr;
+  size_t fixups_bytes = 0;
+  bool fixup_overflow_pending = false;
+  // measured on MI355X (profiles/r01_tune_*.txt): a wave that runs its 64 samples to completion with
+  // steps and events in separate wave-wide phases beats mid-flight refills (12.5 vs 7.6 Gsamples/s)
+  int32_t tune_step_min_lanes = 1, tune_refill_min_lanes = 64;
+  uint32_t tune_bounce_max_blocks = 2048;
   bool primary_valid = false;
   uint32_t primary_n_hits = 0;
   struct PrimaryKey {

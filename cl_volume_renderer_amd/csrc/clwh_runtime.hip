@@ -71,6 +71,9 @@ int clwh_ctx_create_on_stream(int device, void *hip_stream, clwh_ctx **out) {
   c->device = device;
   c->stream = (hipStream_t)hip_stream;
   c->own_stream = false;
+  if (const char *e = std::getenv("CLWH_TUNE_STEP")) c->tune_step_min_lanes = std::max(1, std::min(64, std::atoi(e)));
+  if (const char *e = std::getenv("CLWH_TUNE_REFILL")) c->tune_refill_min_lanes = std::max(1, std::min(64, std::atoi(e)));
+  if (const char *e = std::getenv("CLWH_TUNE_BLOCKS")) c->tune_bounce_max_blocks = (uint32_t)std::max(1, std::atoi(e));
   *out = c;
   return CLWH_OK;
 }
@@ -98,6 +101,7 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
   if (ctx->pix_slot) (void)hipFree(ctx->pix_slot);
   if (ctx->hits) (void)hipFree(ctx->hits);
   if (ctx->render_counters) (void)hipFree(ctx->render_counters);
+  if (ctx->fixups) (void)hipFree(ctx->fixups);
   if (ctx->sdf_counters) (void)hipFree(ctx->sdf_counters);
   if (ctx->sdf_pong) (void)hipFree(ctx->sdf_pong);
   if (ctx->packed) (void)hipFree(ctx->packed);
@@ -108,10 +112,21 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
   return CLWH_OK;
 }
 
+// a render may have overflowed its fix-up buffer (never with sane env-map sizes); the flag is read at
+// the next synchronisation point and reported instead of handing out incomplete results
+static int check_device_flags(clwh_ctx *ctx) {
+  if (!ctx->fixup_overflow_pending || !ctx->render_counters) return CLWH_OK;
+  uint32_t flag = 0;
+  HIP_TRY(hipMemcpyAsync(&flag, ctx->render_counters + 3, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->fixup_overflow_pending = false;
+  return flag ? CLWH_ERR_INTERNAL_OVERFLOW : CLWH_OK;
+}
+
 int clwh_ctx_finish(clwh_ctx *ctx) {
   if (!ctx) return CLWH_ERR_INVALID_VALUE;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return CLWH_OK;
+  return check_device_flags(ctx);
 }
 
 void *clwh_ctx_stream(clwh_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
@@ -247,7 +262,7 @@ int clwh_mem_pull(clwh_ctx *ctx, clwh_mem *mem, void *host, size_t bytes) {
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipMemcpyAsync(host, mem->dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return CLWH_OK;
+  return check_device_flags(ctx);
 }
 
 int clwh_mem_release(clwh_mem *mem) {
@@ -340,7 +355,8 @@ static bool is_image(const clwh_mem *m, int dims_n, int channels, int elem_kind)
 static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *sdf, const TfDev &tf) {
   const int X = (int)volume->dims[0], Y = (int)volume->dims[1], Z = (int)volume->dims[2];
   const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 7) / 8;
-  const size_t bytes = (size_t)NBX * NBY * NBZ * 512u * sizeof(uint32_t);
+  const size_t records = (size_t)NBX * NBY * NBZ * 512u;
+  const size_t bytes = records * (sizeof(uint32_t) + 1u);  // records, then the per-step bytes
   if (ctx->packed_valid && ctx->packed_bytes == bytes && ctx->packed_vol == volume->dptr &&
       ctx->packed_sdf == sdf->dptr && ctx->packed_vol_ver == volume->version &&
       ctx->packed_sdf_ver == sdf->version && !std::memcmp(&ctx->packed_tf, &tf, sizeof tf))
@@ -363,6 +379,7 @@ static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *
   r.X = X; r.Y = Y; r.Z = Z;
   r.NBX = NBX; r.NBY = NBY; r.NBZ = NBZ;
   r.packed = ctx->packed;
+  r.stepb = reinterpret_cast<uint8_t *>(ctx->packed + records);
   r.tf = tf;
   HIP_TRY(launch_repack(r, ctx->stream));
   ctx->packed_vol = volume->dptr;
@@ -418,6 +435,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     if (d->volume->dims[q] != d->sdf->dims[q]) return CLWH_ERR_SIZE_MISMATCH;
   if (d->width == 0 || d->height == 0 || (d->width % 8) != 0 || (d->height % 8) != 0) return CLWH_ERR_BAD_NDRANGE;
   if (d->width > 65535u || d->height > 65535u) return CLWH_ERR_BAD_NDRANGE;  // pixel ids are packed x | y << 16
+  if (d->env->dims[0] > 32768u || d->env->dims[1] > 32768u) return CLWH_ERR_INVALID_VALUE;  // env_fast.hpp bracket
   if (d->volume->dims[0] > 0x7fffffffu || d->volume->dims[1] > 0x7fffffffu || d->volume->dims[2] > 0x7fffffffu)
     return CLWH_ERR_INVALID_VALUE;
   const int world = d->tile_world < 1 ? 1 : d->tile_world;
@@ -468,6 +486,9 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     a.seeds[0] = d->seed;
   }
   tf_to_dev(k->tf, a.tf);
+  a.step_min_lanes = ctx->tune_step_min_lanes;
+  a.refill_min_lanes = ctx->tune_refill_min_lanes;
+  a.bounce_max_blocks = ctx->tune_bounce_max_blocks;
 
   HIP_TRY(hipSetDevice(ctx->device));
   int rc = ensure_packed(ctx, d->volume, d->sdf, a.tf);
@@ -475,6 +496,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   a.packed = ctx->packed;
   a.NBX = (a.X + 7) / 8;
   a.NBY = (a.Y + 7) / 8;
+  a.stepb = reinterpret_cast<const uint8_t *>(ctx->packed + (size_t)a.NBX * a.NBY * ((a.Z + 7) / 8) * 512u);
 
   // ---- primary hits of this camera: rebuilt only when something they depend on changed
   const size_t slots = (size_t)a.num_tile_slots * 64u;
@@ -482,7 +504,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   if (rc != CLWH_OK) return rc;
   rc = grow(ctx, (void **)&ctx->hits, &ctx->hits_bytes, slots * sizeof(HitRec));
   if (rc != CLWH_OK) return rc;
-  if (!ctx->render_counters) HIP_TRY(hipMalloc((void **)&ctx->render_counters, 2 * sizeof(uint32_t)));
+  if (!ctx->render_counters) HIP_TRY(hipMalloc((void **)&ctx->render_counters, 4 * sizeof(uint32_t)));
   a.pix_slot = ctx->pix_slot;
   a.hits = ctx->hits;
   a.counters = ctx->render_counters;
@@ -501,7 +523,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   key.packed_generation = ctx->packed_generation;
   if (!ctx->primary_valid || std::memcmp(&key, &ctx->primary_key, sizeof key) != 0 || a.hit_index_out) {
     ctx->primary_valid = false;
-    HIP_TRY(hipMemsetAsync(ctx->render_counters, 0, 2 * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->render_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
     HIP_TRY(launch_primary(a, ctx->stream));
     uint32_t n_hits = 0;
     HIP_TRY(hipMemcpyAsync(&n_hits, ctx->render_counters, sizeof n_hits, hipMemcpyDeviceToHost, ctx->stream));
@@ -513,7 +535,14 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   a.n_hits = ctx->primary_n_hits;
 
   // ---- the pass: every (hit, seed) item
-  HIP_TRY(hipMemsetAsync(ctx->render_counters + 1, 0, sizeof(uint32_t), ctx->stream));
+  // fix-up records for environment lookups the fast path cannot certify: room for a quarter of the
+  // items, two orders of magnitude above the expected rate for env maps up to 32768 texels wide
+  const size_t fix_cap = std::max<size_t>(((size_t)a.n_hits * (size_t)a.n_seeds) / 4u, 4096u);
+  rc = grow(ctx, (void **)&ctx->fixups, &ctx->fixups_bytes, fix_cap * 128u);
+  if (rc != CLWH_OK) return rc;
+  a.fixups = ctx->fixups;
+  a.fixup_capacity = (uint32_t)std::min<size_t>(ctx->fixups_bytes / 128u, 0x7fffffffu);
+  HIP_TRY(hipMemsetAsync(ctx->render_counters + 1, 0, 3 * sizeof(uint32_t), ctx->stream));
   if (a.contrib_out) HIP_TRY(hipMemsetAsync(a.contrib_out, 0, npx * 16, ctx->stream));  // misses contribute nothing
   hipEvent_t ev_b = nullptr, ev_e = nullptr;
   if (ctx->timing) {
@@ -522,6 +551,8 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     HIP_TRY(hipEventRecord(ev_b, ctx->stream));
   }
   HIP_TRY(launch_bounce(a, ctx->stream));
+  HIP_TRY(launch_env_fixup(a, ctx->stream));
+  ctx->fixup_overflow_pending = true;
   if (ctx->timing) HIP_TRY(hipEventRecord(ev_e, ctx->stream));
   if (d->write_frame && a.frame) HIP_TRY(launch_resolve(a, ctx->stream));
   if (d->frame) d->frame->version++;
@@ -778,6 +809,7 @@ const char *clwh_strerror(int status) {
     case CLWH_ERR_BAD_ARGS: return "CLWH_ERR_BAD_ARGS";
     case CLWH_ERR_BAD_NDRANGE: return "CLWH_ERR_BAD_NDRANGE";
     case CLWH_ERR_SIZE_MISMATCH: return "CLWH_ERR_SIZE_MISMATCH";
+    case CLWH_ERR_INTERNAL_OVERFLOW: return "CLWH_ERR_INTERNAL_OVERFLOW";
     default: return "CLWH_ERR_UNKNOWN";
   }
 }

@@ -8,7 +8,10 @@
 //     bits 24..31  class   (1 + index of the first transfer-function rule the value satisfies, 0 = no
 //                           event; only when no rule reads `gradient`)
 // and one gather per step returns the classification of the new position AND the step length of the
-// next step.  Records are stored in 8x8x8 bricks made of eight 4x4x4 sub-bricks (256 B each, x
+// next step.  When no rule reads `gradient` the march needs even less: a second array keeps ONE BYTE
+// per voxel, bit 7 = "class != 0" (a Hit), bits 0-6 = max(sdf, 0) (the step is max(sdf, 0.5), so
+// negative distances all mean 0.5); the 4-byte record is only fetched at a Hit (colour) and for the
+// 6-tap normal.  Records are stored in 8x8x8 bricks made of eight 4x4x4 sub-bricks (256 B each, x
 // fastest inside), so the 64 rays of an 8x8 pixel tile, which walk a tube a few voxels wide, share
 // a handful of 128-B lines instead of one line per (y,z) row as in the caller's x-fastest layout.
 // The packed volume is derived data: built by k_repack at the first render after the volume, the
@@ -21,14 +24,17 @@ namespace clvr {
 
 struct VolumePacked {
   const uint32_t *__restrict__ rec;
+  const uint8_t *__restrict__ stepb;  // 1 byte per voxel, same brick order: bit7 = class != 0, bits0-6 = max(sdf, 0)
   int X, Y, Z;
   int NBX, NBY;  // bricks per row / per slice
 
+  // coordinates are non-negative and in range; the brick number fits 32 bits for every volume that
+  // fits the GPU (2048^3 has 2^24 bricks), so only the final scale by 512 records is 64-bit
   __host__ __device__ static inline size_t record_index(int x, int y, int z, int nbx, int nby) {
-    const size_t brick = ((size_t)(z >> 3) * (size_t)nby + (size_t)(y >> 3)) * (size_t)nbx + (size_t)(x >> 3);
-    const unsigned sub = (((unsigned)z >> 2) & 1u) * 4u + (((unsigned)y >> 2) & 1u) * 2u + (((unsigned)x >> 2) & 1u);
-    const unsigned inner = ((unsigned)z & 3u) * 16u + ((unsigned)y & 3u) * 4u + ((unsigned)x & 3u);
-    return brick * 512u + sub * 64u + inner;
+    const unsigned ux = (unsigned)x, uy = (unsigned)y, uz = (unsigned)z;
+    const unsigned brick = ((uz >> 3) * (unsigned)nby + (uy >> 3)) * (unsigned)nbx + (ux >> 3);
+    const unsigned inner = ((uz & 4u) << 6) | ((uy & 4u) << 5) | ((ux & 4u) << 4) | ((uz & 3u) << 4) | ((uy & 3u) << 2) | (ux & 3u);
+    return ((size_t)brick << 9) + inner;
   }
 
   // int coordinates (read_imagei(img, int4)): out of range -> border record 0
@@ -41,6 +47,18 @@ struct VolumePacked {
     const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
     if (!(gx >= 0.0f && gy >= 0.0f && gz >= 0.0f && gx < (float)X && gy < (float)Y && gz < (float)Z)) return 0u;
     return rec[record_index((int)gx, (int)gy, (int)gz, NBX, NBY)];
+  }
+
+  // the march's per-step byte (gradient-free transfer functions): one 64-byte line holds a whole 4x4x4
+  // sub-brick, the whole 512^3 array is 128 MiB and stays resident in the 256 MiB Infinity Cache
+  __device__ __forceinline__ unsigned step_i(int x, int y, int z) const {
+    if ((unsigned)x >= (unsigned)X || (unsigned)y >= (unsigned)Y || (unsigned)z >= (unsigned)Z) return 0u;
+    return stepb[record_index(x, y, z, NBX, NBY)];
+  }
+  __device__ __forceinline__ unsigned step_f(float fx, float fy, float fz) const {
+    const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
+    if (!(gx >= 0.0f && gy >= 0.0f && gz >= 0.0f && gx < (float)X && gy < (float)Y && gz < (float)Z)) return 0u;
+    return stepb[record_index((int)gx, (int)gy, (int)gz, NBX, NBY)];
   }
 
   __device__ __forceinline__ static int value_of(uint32_t r) { return (int)(int16_t)(r & 0xFFFFu); }

@@ -7,6 +7,7 @@
 
 #include "clwh_internal.hpp"
 #include "device_math.hpp"
+#include "env_fast.hpp"
 #include "packed_volume.hpp"
 
 namespace clvr {
@@ -143,6 +144,15 @@ __device__ __forceinline__ uint32_t sample_environment_map(const uint32_t *__res
   return env[(size_t)j * (size_t)w + (size_t)i];
 }
 
+// the same lookup through the certified fast path (env_fast.hpp); false = undecided, use the exact one
+__device__ __forceinline__ bool sample_environment_map_fast(const uint32_t *__restrict__ env, int w, int h, f3 d,
+                                                            uint32_t &texel) {
+  int32_t i, j;
+  if (!env_texel_fast(d.x, d.y, d.z, w, h, i, j)) return false;
+  texel = env[(size_t)j * (size_t)w + (size_t)i];
+  return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // marching (utility_ray.cl:112-168)
 template <class Vol>
@@ -185,25 +195,32 @@ template <bool USE_GRAD>
 __device__ __forceinline__ Ray march_to_next_event(const VolumePacked &v, const TfDev &tf, Ray cur, int &event,
                                                    uint32_t &color) {
   int ev = EV_NONE;
-  int sd = v.sdf_at(f2i(cur.origin.x), f2i(cur.origin.y), f2i(cur.origin.z));
-  for (int i = 0; i < 70; ++i) {
-    const float step_size = cl_max((float)sd, 0.5f);
-    cur.origin = cur.origin + cur.direction * step_size;
-    if (exited_volume(v, cur.origin)) { ev = EV_EXIT; break; }
-    const uint32_t r = v.fetch_f(cur.origin.x, cur.origin.y, cur.origin.z);
-    if (USE_GRAD) {
+  if (USE_GRAD) {
+    int sd = v.sdf_at(f2i(cur.origin.x), f2i(cur.origin.y), f2i(cur.origin.z));
+    for (int i = 0; i < 70; ++i) {
+      const float step_size = cl_max((float)sd, 0.5f);
+      cur.origin = cur.origin + cur.direction * step_size;
+      if (exited_volume(v, cur.origin)) { ev = EV_EXIT; break; }
+      const uint32_t r = v.fetch_f(cur.origin.x, cur.origin.y, cur.origin.z);
       const int gradient = (int)(short)f2i(length3(gradient_nn(v, cur.origin)));
       if (tf_eval(tf, VolumePacked::value_of(r), gradient, color)) { ev = EV_HIT; break; }
-    } else {
-      const unsigned cls = VolumePacked::class_of(r);
-      if (cls != 0u) {
+      sd = VolumePacked::sdf_of(r);
+    }
+  } else {
+    unsigned q = v.step_i(f2i(cur.origin.x), f2i(cur.origin.y), f2i(cur.origin.z));
+    for (int i = 0; i < 70; ++i) {
+      const float step_size = cl_max((float)(q & 0x7Fu), 0.5f);
+      cur.origin = cur.origin + cur.direction * step_size;
+      if (exited_volume(v, cur.origin)) { ev = EV_EXIT; break; }
+      q = v.step_f(cur.origin.x, cur.origin.y, cur.origin.z);
+      if (q & 0x80u) {
+        const unsigned cls = VolumePacked::class_of(v.fetch_f(cur.origin.x, cur.origin.y, cur.origin.z));
         const TfRuleDev &rule = tf.rules[cls - 1u];
         if (rule.flags & TF_WRITES_COLOR) color = rule.color;
         ev = EV_HIT;
         break;
       }
     }
-    sd = VolumePacked::sdf_of(r);
   }
   event = ev;
   return cur;

@@ -39,7 +39,7 @@ __device__ __forceinline__ uint32_t xcd_contiguous_slot(uint32_t b, uint32_t nbl
 }
 
 __device__ __forceinline__ VolumePacked make_volume(const RenderArgs &a) {
-  return VolumePacked{a.packed, a.X, a.Y, a.Z, a.NBX, a.NBY};
+  return VolumePacked{a.packed, a.stepb, a.X, a.Y, a.Z, a.NBX, a.NBY};
 }
 
 // number of set bits of `mask` below this lane
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
   const int y = by * 8 + (int)((sub >> 1) & 1u) * 4 + (int)((lane >> 2) & 3u);
   const int z = bz * 8 + (int)((sub >> 2) & 1u) * 4 + (int)(lane >> 4);
   uint32_t r = 0u;
+  uint8_t q = 0u;
   if (x < a.X && y < a.Y && z < a.Z) {
     const size_t i = ((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x;
     const int value = a.volume[i];
@@ -79,8 +80,10 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
       }
     }
     r = ((uint32_t)value & 0xFFFFu) | (((uint32_t)sd & 0xFFu) << 16) | (cls << 24);
+    q = (uint8_t)((cls ? 0x80u : 0u) | (uint32_t)(sd > 0 ? sd : 0));
   }
   a.packed[sub_id * 64u + lane] = r;
+  a.stepb[sub_id * 64u + lane] = q;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -163,8 +166,6 @@ __global__ __launch_bounds__(64) void k_primary(const RenderArgs a) {
 // lanes have no item.
 enum : int { ST_IDLE = 0, ST_MARCH = 1, ST_EVENT = 2 };
 enum : int { EV_START = 3 };            // a freshly fetched item: start distribution ray 1
-constexpr int kStepPhaseMinLanes = 24;  // keep stepping while at least this many lanes march
-constexpr int kRefillMinLanes = 16;     // refill when at least this many lanes are idle
 
 template <int MODE>
 __device__ __forceinline__ void finish_item(const RenderArgs &a, int64_t entry, uint32_t pslot, uint32_t gx,
@@ -187,11 +188,21 @@ __device__ __forceinline__ void finish_item(const RenderArgs &a, int64_t entry, 
   }
 }
 
+// Environment lookups use the certified fast path (env_fast.hpp).  A lookup that cannot be certified
+// (about one in a thousand) does not stall the lane: the sample's pending term {atten*energy, factor,
+// direction} goes into a fix-up record, the lane walks the rest of the sample as usual, and the tiny
+// k_env_fixup launch that follows evaluates the exact binary64 lookup and finishes the arithmetic in
+// the reference's order.  Every sample is accumulated exactly once, by one of the two kernels.
+constexpr int kFixupDwords = 32;  // one record = 128 B: header[4] bv_before[3] n_pending[1] 2 x {P[3] factor dir[3]}
+
 template <bool USE_GRAD, int MODE>
 __global__ __launch_bounds__(256) void k_bounce(const RenderArgs a) {
   const VolumePacked vol = make_volume(a);
+  // counters: [0] hits, [1] queue head, [2] fix-up records, [3] fix-up overflow flag
   const uint32_t total = a.n_hits * (uint32_t)a.n_seeds;
   const unsigned lane = lane_id();
+  int fix = -1;    // fix-up record of the lane's sample (-1: none, -2: dropped, the buffer overflowed)
+  int npend = 0;   // pending environment terms written to it
 
   // the sample
   uint32_t gx = 0, gy = 0, pslot = 0;
@@ -214,7 +225,7 @@ __global__ __launch_bounds__(256) void k_bounce(const RenderArgs a) {
     // ---- refill idle lanes from the work queue (ballot + prefix compaction) ----------------------
     const unsigned long long idle_mask = __ballot(st == ST_IDLE);
     const int n_idle = __popcll(idle_mask);
-    if (!exhausted && n_idle > 0 && (n_idle >= kRefillMinLanes || __ballot(st == ST_MARCH) == 0ull)) {
+    if (!exhausted && n_idle > 0 && (n_idle >= a.refill_min_lanes || __ballot(st == ST_MARCH) == 0ull)) {
       uint32_t base = 0u;
       const int leader = __ffsll((long long)idle_mask) - 1;
       if ((int)lane == leader) base = atomicAdd(&a.counters[1], (uint32_t)n_idle);
@@ -224,6 +235,8 @@ __global__ __launch_bounds__(256) void k_bounce(const RenderArgs a) {
         const uint32_t idx = base + prefix_count(idle_mask);
         if (idx < total) {
           const uint32_t s = idx / a.n_hits, h = idx - s * a.n_hits;
+          fix = -1;
+          npend = 0;
           const uint4 *src = reinterpret_cast<const uint4 *>(&a.hits[h]);
           const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
           hit_origin = f3{__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
@@ -268,15 +281,19 @@ __global__ __launch_bounds__(256) void k_bounce(const RenderArgs a) {
             ev = EV_EXIT;
             st = ST_EVENT;
           } else {
-            const uint32_t r = vol.fetch_f(ray.origin.x, ray.origin.y, ray.origin.z);
             bool is_hit;
+            int next_sd;
             if (USE_GRAD) {
+              const uint32_t r = vol.fetch_f(ray.origin.x, ray.origin.y, ray.origin.z);
               const int gradient = (int)(short)f2i(length3(gradient_nn(vol, ray.origin)));
               is_hit = tf_eval(a.tf, VolumePacked::value_of(r), gradient, color);
+              next_sd = VolumePacked::sdf_of(r);
             } else {
-              const unsigned cls = VolumePacked::class_of(r);
-              is_hit = cls != 0u;
+              const unsigned q = vol.step_f(ray.origin.x, ray.origin.y, ray.origin.z);
+              is_hit = (q & 0x80u) != 0u;
+              next_sd = (int)(q & 0x7Fu);
               if (is_hit) {
+                const unsigned cls = VolumePacked::class_of(vol.fetch_f(ray.origin.x, ray.origin.y, ray.origin.z));
                 const TfRuleDev &rule = a.tf.rules[cls - 1u];
                 if (rule.flags & TF_WRITES_COLOR) color = rule.color;
               }
@@ -288,11 +305,11 @@ __global__ __launch_bounds__(256) void k_bounce(const RenderArgs a) {
               ev = EV_NONE;
               st = ST_EVENT;
             } else {
-              sd = VolumePacked::sdf_of(r);
+              sd = next_sd;
             }
           }
         }
-      } while (__popcll(__ballot(st == ST_MARCH)) >= kStepPhaseMinLanes);
+      } while (__popcll(__ballot(st == ST_MARCH)) >= a.step_min_lanes);
     }
 
     // ---- event phase: every parked lane handles its event; the bounce is one shared block ---------
@@ -306,11 +323,40 @@ __global__ __launch_bounds__(256) void k_bounce(const RenderArgs a) {
       if (ev == EV_EXIT) {
         // ray_marching.cl:54-62: left the volume -> environment light ends this distribution ray
         const float factor = 8.0f / (float)i;
-        const uint32_t light = sample_environment_map(a.env, a.env_w, a.env_h, ray.direction);
-        // uint += float: promote, add, truncate back
-        bv_r = f2u((float)bv_r + atten * r_energy * (float)(light & 255u) * factor / 1.0f);
-        bv_g = f2u((float)bv_g + atten * g_energy * (float)((light >> 8) & 255u) * factor / 1.0f);
-        bv_b = f2u((float)bv_b + atten * b_energy * (float)((light >> 16) & 255u) * factor / 1.0f);
+        const float p_r = atten * r_energy, p_g = atten * g_energy, p_b = atten * b_energy;
+        uint32_t light = 0u;
+        bool certain = (fix == -1) && sample_environment_map_fast(a.env, a.env_w, a.env_h, ray.direction, light);
+        if (certain) {
+          // uint += float: promote, add, truncate back
+          bv_r = f2u((float)bv_r + p_r * (float)(light & 255u) * factor / 1.0f);
+          bv_g = f2u((float)bv_g + p_g * (float)((light >> 8) & 255u) * factor / 1.0f);
+          bv_b = f2u((float)bv_b + p_b * (float)((light >> 16) & 255u) * factor / 1.0f);
+        } else {
+          if (fix == -1) {
+            // first undecided lookup of this sample: open a fix-up record
+            const uint32_t slot = atomicAdd(&a.counters[2], 1u);
+            if (slot < a.fixup_capacity) {
+              fix = (int)slot;
+              uint32_t *rec = a.fixups + (size_t)slot * kFixupDwords;
+              rec[0] = pslot;
+              rec[1] = (uint32_t)((uint64_t)entry & 0xFFFFFFFFull);
+              rec[2] = (uint32_t)((uint64_t)entry >> 32);
+              rec[3] = gx | (gy << 16);
+              rec[4] = bv_r; rec[5] = bv_g; rec[6] = bv_b;
+            } else {
+              a.counters[3] = 1u;  // reported by the host as an error; the sample is dropped
+              fix = -2;
+            }
+          }
+          if (fix >= 0) {
+            uint32_t *e = a.fixups + (size_t)fix * kFixupDwords + 8 + 7 * npend;
+            e[0] = __float_as_uint(p_r); e[1] = __float_as_uint(p_g); e[2] = __float_as_uint(p_b);
+            e[3] = __float_as_uint(factor);
+            e[4] = __float_as_uint(ray.direction.x); e[5] = __float_as_uint(ray.direction.y);
+            e[6] = __float_as_uint(ray.direction.z);
+            npend += 1;
+          }
+        }
         o += 1;
         start_path = true;
       } else if (ev == EV_HIT) {
@@ -342,7 +388,8 @@ __global__ __launch_bounds__(256) void k_bounce(const RenderArgs a) {
 
       if (start_path) {
         if (o > 2) {
-          finish_item<MODE>(a, entry, pslot, gx, gy, bv_r, bv_g, bv_b);
+          if (fix == -1) finish_item<MODE>(a, entry, pslot, gx, gy, bv_r, bv_g, bv_b);
+          else if (fix >= 0) a.fixups[(size_t)fix * kFixupDwords + 7] = (uint32_t)npend;  // k_env_fixup finishes it
           st = ST_IDLE;
         } else {
           // ray_marching.cl:48: bounce from the primary hit around the primary normal
@@ -376,11 +423,39 @@ __global__ __launch_bounds__(256) void k_bounce(const RenderArgs a) {
 
       if (st == ST_EVENT) {
         // start (or continue) a march: its first SDF read is at trunc(origin) (utility_ray.cl:148-150)
-        sd = vol.sdf_at(f2i(ray.origin.x), f2i(ray.origin.y), f2i(ray.origin.z));
+        if (USE_GRAD) sd = vol.sdf_at(f2i(ray.origin.x), f2i(ray.origin.y), f2i(ray.origin.z));
+        else sd = (int)(vol.step_i(f2i(ray.origin.x), f2i(ray.origin.y), f2i(ray.origin.z)) & 0x7Fu);
         steps_left = 70;
         st = ST_MARCH;
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_env_fixup: one lane per fix-up record; exact lookups, then the reference's arithmetic in its order
+template <int MODE>
+__global__ __launch_bounds__(256) void k_env_fixup(const RenderArgs a) {
+  uint32_t n = a.counters[2];
+  if (n > a.fixup_capacity) n = a.fixup_capacity;
+  for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    const uint32_t *rec = a.fixups + (size_t)k * kFixupDwords;
+    const uint32_t pslot = rec[0];
+    const int64_t entry = (int64_t)(((uint64_t)rec[2] << 32) | (uint64_t)rec[1]);
+    const uint32_t gx = rec[3] & 0xFFFFu, gy = rec[3] >> 16;
+    uint32_t bv_r = rec[4], bv_g = rec[5], bv_b = rec[6];
+    const uint32_t npend = rec[7];
+    for (uint32_t q = 0; q < npend && q < 2u; ++q) {
+      const uint32_t *e = rec + 8 + 7 * q;
+      const float p_r = __uint_as_float(e[0]), p_g = __uint_as_float(e[1]), p_b = __uint_as_float(e[2]);
+      const float factor = __uint_as_float(e[3]);
+      const f3 d = f3{__uint_as_float(e[4]), __uint_as_float(e[5]), __uint_as_float(e[6])};
+      const uint32_t light = sample_environment_map(a.env, a.env_w, a.env_h, d);
+      bv_r = f2u((float)bv_r + p_r * (float)(light & 255u) * factor / 1.0f);
+      bv_g = f2u((float)bv_g + p_g * (float)((light >> 8) & 255u) * factor / 1.0f);
+      bv_b = f2u((float)bv_b + p_b * (float)((light >> 16) & 255u) * factor / 1.0f);
+    }
+    finish_item<MODE>(a, entry, pslot, gx, gy, bv_r, bv_g, bv_b);
   }
 }
 
@@ -458,7 +533,7 @@ hipError_t launch_bounce(const RenderArgs &a, hipStream_t s) {
   if (total == 0) return hipSuccess;
   // persistent grid: enough waves to fill the chip (256 CUs x 32 waves), never more than the work
   const uint64_t waves_needed = (total + 63u) / 64u;
-  const unsigned blocks = (unsigned)std::min<uint64_t>((waves_needed + 3u) / 4u, 2048u);
+  const unsigned blocks = (unsigned)std::min<uint64_t>((waves_needed + 3u) / 4u, (uint64_t)a.bounce_max_blocks);
   const dim3 grid(blocks), block(256);
   const bool g = a.tf.uses_gradient != 0;
   if (a.mode == CLWH_ACCUM_VOXEL_CACHE) {
@@ -468,6 +543,16 @@ hipError_t launch_bounce(const RenderArgs &a, hipStream_t s) {
     if (g) hipLaunchKernelGGL((k_bounce<true, CLWH_ACCUM_IMAGE_SPACE>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((k_bounce<false, CLWH_ACCUM_IMAGE_SPACE>), grid, block, 0, s, a);
   }
+  return hipGetLastError();
+}
+
+// finish the samples whose environment lookups the fast path could not certify
+hipError_t launch_env_fixup(const RenderArgs &a, hipStream_t s) {
+  if ((uint64_t)a.n_hits * (uint64_t)a.n_seeds == 0) return hipSuccess;
+  if (a.mode == CLWH_ACCUM_VOXEL_CACHE)
+    hipLaunchKernelGGL(k_env_fixup<CLWH_ACCUM_VOXEL_CACHE>, dim3(64), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_env_fixup<CLWH_ACCUM_IMAGE_SPACE>, dim3(64), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

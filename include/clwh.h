@@ -38,7 +38,8 @@ enum clwh_status {
   CLWH_ERR_TF_UNSUPPORTED = 6, /* the prepended transfer-function source is outside the grammar */
   CLWH_ERR_BAD_ARGS = 7,       /* wrong number / kind of kernel arguments */
   CLWH_ERR_BAD_NDRANGE = 8,    /* global not a multiple of local, zero size, ... */
-  CLWH_ERR_SIZE_MISMATCH = 9
+  CLWH_ERR_SIZE_MISMATCH = 9,
+  CLWH_ERR_INTERNAL_OVERFLOW = 10 /* a device-side work buffer overflowed; results of the last render are incomplete */
 };
 
 /* element kinds of an image channel: (signedness, sizeof) as clw_image picks them

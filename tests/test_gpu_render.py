@@ -236,3 +236,12 @@ def test_primary_hits_follow_camera_volume_and_tf_changes(gpu_ctx, orc):
     assert np.array_equal(g.cache.pull(), o3.cache)
     assert np.array_equal(g.frame.pull(), o3.frame)
     g.release()
+
+
+def test_uncertified_env_lookups_are_fixed_up_exactly(gpu_ctx, orc):
+    """a wide environment map makes the fast lookup's bracket straddle texel boundaries often (~1 %):
+    those samples go through the fix-up records + exact binary64 lookup and must still be bit-exact."""
+    vol, sdf, env, tf = small_scene(orc, 48, env_wh=(16384, 8192))
+    pos, d = look_at_centre(vol, [-20, 40, -20])
+    st = _compare_passes(orc, gpu_ctx, vol, sdf, env, tf, (256, 192), pos, d, scene.glibc_rand(4))
+    assert st["hits"] > 5000

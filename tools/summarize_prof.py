@@ -33,7 +33,7 @@ def main(d):
             continue
         print("\n== %s: mean per dispatch ==" % sub)
         for k, cs in acc.items():
-            if "render" not in k and "sdf" not in k:
+            if not any(t in k for t in ("render", "sdf", "bounce", "primary", "repack", "fixup", "resolve")):
                 continue
             for c, v in sorted(cs.items()):
                 m = sum(v) / len(v)
