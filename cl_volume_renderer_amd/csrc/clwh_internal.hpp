@@ -109,7 +109,22 @@ hipError_t launch_bounce(const RenderArgs &a, hipStream_t s);
 hipError_t launch_env_fixup(const RenderArgs &a, hipStream_t s);
 hipError_t launch_resolve(const RenderArgs &a, hipStream_t s);
 hipError_t launch_accum_resolve(const RenderArgs &a, const float4 *accum_all, hipStream_t s);
+// ---- fused SDF build: one breadth-first layer over the active 8x8x8 tiles (sdf_kernels.hip)
+struct SdfFrontArgs {
+  int8_t *sdf;
+  int32_t X, Y, Z;
+  int32_t TX, TY, TZ;         // 8x8x8 tiles per axis
+  const uint8_t *flags_cur;   // tiles that settled voxels in the previous layer (or hold |v| == 1 for layer 1)
+  uint8_t *flags_next;        // tiles that settle voxels in this layer
+  uint8_t *flags_clear;       // third buffer, zeroed here for the layer after next
+  int32_t iteration;
+  int32_t max_iterations;
+  int32_t *counters;          // [i] != 0: layer i settled a voxel to a value < max_iterations; [0] != 0: some |v| == 1
+};
+
 hipError_t launch_sdf_base(const SdfArgs &a, hipStream_t s);
+hipError_t launch_sdf_base_front(const SdfArgs &a, uint8_t *flags, int32_t TX, int32_t TY, hipStream_t s);
+hipError_t launch_sdf_front(const SdfFrontArgs &a, hipStream_t s);
 hipError_t launch_sdf_layer(const SdfArgs &a, hipStream_t s);
 
 }  // namespace clvr
@@ -142,9 +157,9 @@ struct clwh_ctx {
     uint64_t packed_generation;
   } primary_key{};
   uint64_t packed_generation = 0;
-  int32_t *sdf_counters = nullptr;  // 2 x 160 ints (counters, done)
-  int8_t *sdf_pong = nullptr;
-  size_t sdf_pong_bytes = 0;
+  int32_t *sdf_counters = nullptr;  // 160 ints: settled voxels per layer
+  uint8_t *sdf_flags = nullptr;     // 3 x tiles bytes (current / next / being cleared)
+  size_t sdf_flags_bytes = 0;
   // derived packed volume (single entry, keyed by the source objects' identity + version and the TF)
   uint32_t *packed = nullptr;
   size_t packed_bytes = 0;

@@ -103,7 +103,7 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
   if (ctx->render_counters) (void)hipFree(ctx->render_counters);
   if (ctx->fixups) (void)hipFree(ctx->fixups);
   if (ctx->sdf_counters) (void)hipFree(ctx->sdf_counters);
-  if (ctx->sdf_pong) (void)hipFree(ctx->sdf_pong);
+  if (ctx->sdf_flags) (void)hipFree(ctx->sdf_flags);
   if (ctx->packed) (void)hipFree(ctx->packed);
   for (hipEvent_t e : ctx->ev_begin) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_end) (void)hipEventDestroy(e);
@@ -614,62 +614,76 @@ int clwh_sdf_build(clwh_ctx *ctx, clwh_mem *volume, const char *tf_source, clwh_
   if (rc != CLWH_OK) return rc;
 
   HIP_TRY(hipSetDevice(ctx->device));
-  const size_t n = sdf->bytes;
-  if (ctx->sdf_pong_bytes < n) {
-    if (ctx->sdf_pong) {
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      HIP_TRY(hipFree(ctx->sdf_pong));
-      ctx->sdf_pong = nullptr;
-      ctx->sdf_pong_bytes = 0;
-    }
-    HIP_TRY(hipMalloc((void **)&ctx->sdf_pong, n));
-    ctx->sdf_pong_bytes = n;
-  }
+  const int X = (int)volume->dims[0], Y = (int)volume->dims[1], Z = (int)volume->dims[2];
+  const int TX = (X + 7) / 8, TY = (Y + 7) / 8, TZ = (Z + 7) / 8;
+  const size_t n_tiles = (size_t)TX * TY * TZ;
+  rc = grow(ctx, (void **)&ctx->sdf_flags, &ctx->sdf_flags_bytes, 3 * n_tiles);
+  if (rc != CLWH_OK) return rc;
   constexpr int kSlots = 160;
-  if (!ctx->sdf_counters) HIP_TRY(hipMalloc((void **)&ctx->sdf_counters, 2 * kSlots * sizeof(int32_t)));
-  HIP_TRY(hipMemsetAsync(ctx->sdf_counters, 0, 2 * kSlots * sizeof(int32_t), ctx->stream));
+  if (!ctx->sdf_counters) HIP_TRY(hipMalloc((void **)&ctx->sdf_counters, kSlots * sizeof(int32_t)));
+  HIP_TRY(hipMemsetAsync(ctx->sdf_counters, 0, kSlots * sizeof(int32_t), ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->sdf_flags, 0, 3 * n_tiles, ctx->stream));
 
-  SdfArgs a;
+  SdfArgs b;
+  std::memset(&b, 0, sizeof b);
+  b.volume = (const int16_t *)volume->dptr;
+  b.X = X; b.Y = Y; b.Z = Z;
+  b.ping = (int8_t *)sdf->dptr;
+  b.max_iterations = sdf_max_iterations(volume);
+  b.counters = ctx->sdf_counters;  // [0] = number of |v| == 1 voxels
+  tf_to_dev(tf, b.tf);
+  uint8_t *flags[3] = {ctx->sdf_flags, ctx->sdf_flags + n_tiles, ctx->sdf_flags + 2 * n_tiles};
+  HIP_TRY(launch_sdf_base_front(b, flags[1], TX, TY, ctx->stream));  // layer 1 reads flags[1 % 3]
+
+  SdfFrontArgs a;
   std::memset(&a, 0, sizeof a);
-  a.volume = (const int16_t *)volume->dptr;
-  a.X = (int32_t)volume->dims[0];
-  a.Y = (int32_t)volume->dims[1];
-  a.Z = (int32_t)volume->dims[2];
-  a.max_iterations = sdf_max_iterations(volume);
+  a.sdf = (int8_t *)sdf->dptr;
+  a.X = X; a.Y = Y; a.Z = Z;
+  a.TX = TX; a.TY = TY; a.TZ = TZ;
+  a.max_iterations = b.max_iterations;
   a.counters = ctx->sdf_counters;
-  a.done = ctx->sdf_counters + kSlots;
-  a.counter_out = nullptr;
-  tf_to_dev(tf, a.tf);
 
-  int8_t *member = (int8_t *)sdf->dptr, *other = ctx->sdf_pong;
-  a.ping = member;
-  a.pong = other;
-  HIP_TRY(launch_sdf_base(a, ctx->stream));
-
-  const int bound = a.max_iterations + (a.max_iterations % 2) + 1;  // signed_distance_field.cpp:22
-  std::vector<int32_t> host(2 * kSlots, 0);
-  int launches = bound;
+  // layers that can still settle a voxel: i + 1 < max_iterations; the host looks at the per-layer
+  // counts every 16 launches and stops once a layer settled nothing (nothing can change after it)
+  const int last_layer = a.max_iterations - 2;
+  std::vector<int32_t> settled(kSlots, 0);
   int i = 1;
-  bool finished = false;
-  while (i <= bound && !finished) {
-    const int chunk_end = std::min(bound, i + 7);
+  bool quiet = false;
+  while (i <= last_layer && !quiet) {
+    const int chunk_end = std::min(last_layer, i + 15);
     for (; i <= chunk_end; ++i) {
       a.iteration = i;
-      a.ping = (i & 1) ? member : other;  // odd layers read the member image, even ones read the other
-      a.pong = (i & 1) ? other : member;
-      HIP_TRY(launch_sdf_layer(a, ctx->stream));
+      a.flags_cur = flags[i % 3];
+      a.flags_next = flags[(i + 1) % 3];
+      a.flags_clear = flags[(i + 2) % 3];
+      HIP_TRY(launch_sdf_front(a, ctx->stream));
     }
-    HIP_TRY(hipMemcpyAsync(host.data(), ctx->sdf_counters, 2 * kSlots * sizeof(int32_t), hipMemcpyDeviceToHost,
-                           ctx->stream));
+    HIP_TRY(hipMemcpyAsync(settled.data(), ctx->sdf_counters, kSlots * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int j = 1; j < i; j += 2)
-      if (host[j] == 0) {
+    for (int j = 1; j < i; ++j)
+      if (settled[j] == 0) quiet = true;
+  }
+  if (i <= 1) {  // no layer ran (max_iterations <= 2): still need the base counts
+    HIP_TRY(hipMemcpyAsync(settled.data(), ctx->sdf_counters, kSlots * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  if (n_launches) {
+    // what the reference's host loop would have run (app/signed_distance_field.cpp:22-32): its counter at
+    // layer i counts the voxels holding i plus those settling to i+1 (< max); it stops at the first odd
+    // layer whose counter is zero, or at the bound
+    const int bound = a.max_iterations + (a.max_iterations % 2) + 1;
+    int launches = bound;
+    for (int j = 1; j <= bound; ++j) {
+      const int64_t holding = (j == 1) ? settled[0] : (j - 1 < kSlots ? settled[j - 1] : 0);
+      const int64_t settling = j < kSlots ? settled[j] : 0;
+      const bool holding_counts = j < a.max_iterations;  // a voxel holding j is rewritten only while j < max
+      if ((j & 1) && (holding_counts ? holding : 0) + settling == 0) {
         launches = j;
-        finished = true;
         break;
       }
+    }
+    *n_launches = launches;
   }
-  if (n_launches) *n_launches = launches;
   sdf->version++;
   return CLWH_OK;
 }

@@ -115,6 +115,175 @@ __global__ __launch_bounds__(256) void k_sdf_layer(const SdfArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused build (clwh_sdf_build): the layer iteration is a breadth-first distance transform over the
+// "8 corner neighbours" graph -- a homogeneous voxel settles at layer i to +-(i+1) exactly when a corner
+// neighbour holds +-i (signed_distance_field.cl:56-112; its neighbourhood is sign-uniform by
+// construction of the base image).  Only voxels next to the layer-i front can change at layer i, so
+// the fused build works IN PLACE on the caller's SDF image and visits only the 8x8x8 tiles whose
+// 27-neighbourhood changed in the previous layer.  Reading a neighbour that another wave settles
+// concurrently is harmless: it moves from +-max to +-(i+1), both > i, and signs never change, so the
+// "min |neighbour| == i" test sees the same answer either way.  The result is the fixed point the
+// reference's ping/pong loop converges to (both of its buffers hold every settled voxel).
+// base image for the fused build: same values as k_sdf_base into ONE buffer, plus the layer-1 tile flags
+template <bool USE_GRAD>
+__global__ __launch_bounds__(256) void k_sdf_base_front(const SdfArgs a, uint8_t *flags, int32_t TX, int32_t TY) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const int z = blockIdx.z;
+  bool is_one = false;
+  if (x < a.X) {
+    const VolumeIntLinear v{a.volume, a.X, a.Y, a.Z};
+    const bool e = event_at<USE_GRAD>(v, a.tf, x, y, z);
+    bool homogenous = true;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int nx = min(max(x + ((c & 1) ? 1 : -1), 0), a.X - 1);
+      const int ny = min(max(y + ((c & 2) ? 1 : -1), 0), a.Y - 1);
+      const int nz = min(max(z + ((c & 4) ? 1 : -1), 0), a.Z - 1);
+      homogenous &= (event_at<USE_GRAD>(v, a.tf, nx, ny, nz) == e);
+    }
+    int r = e ? -1 : 1;
+    if (homogenous) r *= a.max_iterations;
+    a.ping[((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x] = (int8_t)r;
+    is_one = (r == 1 || r == -1);
+  }
+  const unsigned long long m = __ballot(is_one);
+  if (is_one) {
+    // layer 1 must visit every tile that holds a corner neighbour of a |v| == 1 voxel
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned group = (unsigned)(m >> (lane & ~7u)) & 0xFFu;
+    const bool first_of_tile = (group & ((1u << (lane & 7u)) - 1u)) == 0u;
+    const size_t own = ((size_t)(z >> 3) * TY + (size_t)(y >> 3)) * TX + (size_t)(x >> 3);
+    if (first_of_tile) flags[own] = 1;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int nx = min(max(x + ((c & 1) ? 1 : -1), 0), a.X - 1);
+      const int ny = min(max(y + ((c & 2) ? 1 : -1), 0), a.Y - 1);
+      const int nz = min(max(z + ((c & 4) ? 1 : -1), 0), a.Z - 1);
+      const size_t t = ((size_t)(nz >> 3) * TY + (size_t)(ny >> 3)) * TX + (size_t)(nx >> 3);
+      if (t != own) flags[t] = 1;
+    }
+  }
+  // only zero / non-zero of the counts is ever needed (loop termination), so a plain store replaces
+  // the same-address atomics that would serialise two million waves at one L2 channel
+  if (m != 0ull && (threadIdx.x & 63u) == (unsigned)__ffsll((long long)m) - 1u) a.counters[0] = 1;
+}
+
+constexpr unsigned kFrontTilesPerBlock = 64;  // one wave tests 64 tiles, four waves process the active ones
+constexpr int kRowStride = 16, kSliceStride = 160;  // LDS image of a tile + halo: rows of 16 bytes [x0-4, x0+12)
+
+__global__ __launch_bounds__(256) void k_sdf_front(const SdfFrontArgs a) {
+  __shared__ uint32_t s_list[kFrontTilesPerBlock];
+  __shared__ uint32_t s_count;
+  __shared__ __attribute__((aligned(16))) int8_t s_region[4][10 * kSliceStride];
+  const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+  const uint32_t n_tiles = (uint32_t)a.TX * (uint32_t)a.TY * (uint32_t)a.TZ;
+  if (tid == 0) s_count = 0u;
+  __syncthreads();
+
+  // which of this block's tiles can change in this layer?  (strided assignment: the front is a surface,
+  // consecutive tiles are active together; spreading a block's tiles over the volume balances the blocks)
+  if (wave == 0u) {
+    const uint32_t tile = lane * gridDim.x + blockIdx.x;
+    bool active = false;
+    if (tile < n_tiles) {
+      a.flags_clear[tile] = 0;
+      active = a.flags_cur[tile] != 0;  // set by whoever settled a voxel next to (or inside) this tile
+    }
+    const unsigned long long am = __ballot(active);
+    if (active) s_list[__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u))] = tile;
+    if (lane == 0u) s_count = (uint32_t)__popcll(am);
+  }
+  __syncthreads();
+  const uint32_t n_active = s_count;
+  const int it = a.iteration;
+  const bool rows_aligned = (a.X & 3) == 0;
+
+  for (uint32_t k0 = 0; k0 < n_active; k0 += 4u) {
+    const uint32_t k = k0 + wave;
+    const bool have = k < n_active;
+    int x0 = 0, y0 = 0, z0 = 0;
+    uint32_t t = 0u;
+    if (have) {
+      t = s_list[k];
+      x0 = (int)(t % (uint32_t)a.TX) * 8;
+      y0 = (int)((t / (uint32_t)a.TX) % (uint32_t)a.TY) * 8;
+      z0 = (int)(t / ((uint32_t)a.TX * (uint32_t)a.TY)) * 8;
+      // tile + 1-voxel halo, neighbour coordinates clamped to the volume (signed_distance_field.cl:72)
+      const bool wide = rows_aligned && x0 >= 4 && x0 + 12 <= a.X;  // one aligned 16-byte load per row
+      for (unsigned r = lane; r < 100u; r += 64u) {
+        const int rz = (int)(r / 10u), ry = (int)(r % 10u);
+        const int gz = min(max(z0 - 1 + rz, 0), a.Z - 1), gy = min(max(y0 - 1 + ry, 0), a.Y - 1);
+        const int8_t *row = a.sdf + ((size_t)gz * (size_t)a.Y + (size_t)gy) * (size_t)a.X;
+        int8_t *dst = &s_region[wave][rz * kSliceStride + ry * kRowStride];
+        if (wide) {
+          *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(row + x0 - 4);
+        } else {
+#pragma unroll
+          for (int rx = 0; rx < 10; ++rx) dst[3 + rx] = row[min(max(x0 - 1 + rx, 0), a.X - 1)];
+        }
+      }
+    }
+    __syncthreads();
+    int settled = 0;
+    unsigned face_mask = 0u;  // which faces of the tile this lane's settled voxels lie on: -x +x -y +y -z +z
+    if (have) {
+      const int ly = (int)(lane & 7u), lz = (int)(lane >> 3);
+      const int y = y0 + ly, z = z0 + lz;
+      if (y < a.Y && z < a.Z) {
+        const int8_t *c = &s_region[wave][(lz + 1) * kSliceStride + (ly + 1) * kRowStride + 4];
+        int8_t *out = a.sdf + ((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x0;
+#pragma unroll
+        for (int lx = 0; lx < 8; ++lx) {
+          if (x0 + lx >= a.X) break;
+          const int v = c[lx];
+          if (abs(v) > it) {
+            int nd = 127, abs_added = 0, added = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const int nv = c[lx + ((q & 1) ? 1 : -1) + ((q & 2) ? kRowStride : -kRowStride) +
+                               ((q & 4) ? kSliceStride : -kSliceStride)];
+              const int an = (int)(int8_t)abs(nv);
+              abs_added += an;
+              added += nv;
+              nd = min(nd, an);
+            }
+            if (abs(added) == abs_added && nd != 0 && nd == it && it + 1 < a.max_iterations) {
+              // the reference only writes (and counts) values below max_iterations; +-max stays as it is
+              out[lx] = (int8_t)(v < 0 ? -(it + 1) : (it + 1));
+              ++settled;
+              face_mask |= (lx == 0 ? 1u : 0u) | (lx == 7 ? 2u : 0u) | (ly == 0 ? 4u : 0u) | (ly == 7 ? 8u : 0u) |
+                           (lz == 0 ? 16u : 0u) | (lz == 7 ? 32u : 0u);
+            }
+          }
+        }
+      }
+    }
+    // per wave: count, and flag every tile that holds a corner neighbour of a voxel settled here: the
+    // tile itself and the (up to 26) neighbours its settled boundary voxels touch
+    const unsigned long long sm = __ballot(settled > 0);
+    if (have && sm != 0ull) {
+      int total = settled;
+      unsigned touch = face_mask;
+      for (int off = 32; off > 0; off >>= 1) {
+        total += __shfl_xor(total, off);
+        touch |= (unsigned)__shfl_xor((int)touch, off);
+      }
+      if (lane == 0u && total > 0) a.counters[it] = 1;  // non-zero marker (see k_sdf_base_front)
+      if (lane < 27u) {
+        const int dx = (int)(lane % 3u) - 1, dy = (int)((lane / 3u) % 3u) - 1, dz = (int)(lane / 9u) - 1;
+        const bool ok_x = dx == 0 || (touch & (dx < 0 ? 1u : 2u)), ok_y = dy == 0 || (touch & (dy < 0 ? 4u : 8u)),
+                   ok_z = dz == 0 || (touch & (dz < 0 ? 16u : 32u));
+        const int nx = x0 / 8 + dx, ny = y0 / 8 + dy, nz = z0 / 8 + dz;
+        if (ok_x && ok_y && ok_z && nx >= 0 && ny >= 0 && nz >= 0 && nx < a.TX && ny < a.TY && nz < a.TZ)
+          a.flags_next[((size_t)nz * a.TY + ny) * a.TX + nx] = 1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 static unsigned sdf_block(const SdfArgs &a) { return a.X <= 64 ? 64u : (a.X <= 128 ? 128u : 256u); }
 static dim3 sdf_grid(const SdfArgs &a) {
   const unsigned b = sdf_block(a);
@@ -126,6 +295,20 @@ hipError_t launch_sdf_base(const SdfArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_sdf_base<true>, sdf_grid(a), dim3(sdf_block(a)), 0, s, a);
   else
     hipLaunchKernelGGL(k_sdf_base<false>, sdf_grid(a), dim3(sdf_block(a)), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_sdf_base_front(const SdfArgs &a, uint8_t *flags, int32_t TX, int32_t TY, hipStream_t s) {
+  if (a.tf.uses_gradient)
+    hipLaunchKernelGGL(k_sdf_base_front<true>, sdf_grid(a), dim3(sdf_block(a)), 0, s, a, flags, TX, TY);
+  else
+    hipLaunchKernelGGL(k_sdf_base_front<false>, sdf_grid(a), dim3(sdf_block(a)), 0, s, a, flags, TX, TY);
+  return hipGetLastError();
+}
+
+hipError_t launch_sdf_front(const SdfFrontArgs &a, hipStream_t s) {
+  const uint32_t n_tiles = (uint32_t)a.TX * (uint32_t)a.TY * (uint32_t)a.TZ;
+  hipLaunchKernelGGL(k_sdf_front, dim3((n_tiles + kFrontTilesPerBlock - 1u) / kFrontTilesPerBlock), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
