@@ -58,7 +58,8 @@ def _stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
-    cmd = [HIPCC] + FLAGS + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    extra = os.environ.get("CLVR_EXTRA_HIPCC_FLAGS", "").split()
+    cmd = [HIPCC] + FLAGS + extra + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -61,7 +61,7 @@ struct RenderArgs {
   float4 *accum;           // tile-major float4 per pixel slot (mode 1)
   uint32_t *pix_slot;      // tile-major, per pixel: PIX_HIT | hit index, or the miss colour
   HitRec *hits;            // compacted primary hits of this camera
-  uint32_t *counters;      // [0] hits (k_primary), [1] queue head, [2] fix-up records, [3] fix-up overflow flag
+  uint32_t *counters;      // [0] hits (k_primary), [2] fix-up records, [3] fix-up overflow flag, [32*(q+1)] unit-queue heads, one per 128-B line
   uint32_t *fixups;        // 128-byte records of samples whose env lookup needs the exact route
   uint32_t fixup_capacity;
   uint32_t n_hits;         // host copy of counters[0] (valid for k_bounce / k_resolve)
@@ -72,8 +72,10 @@ struct RenderArgs {
   int32_t seeds[CLWH_MAX_SEEDS];
   // scheduling knobs of k_bounce (defaults in clwh_runtime.hip; CLWH_TUNE_* override for experiments)
   int32_t step_min_lanes;    // keep stepping while at least this many lanes march
-  int32_t refill_min_lanes;  // refill when at least this many lanes are idle
   uint32_t bounce_max_blocks;  // persistent grid size (256-thread blocks)
+  int32_t unit_group;          // chunks per queue group (see k_bounce refill)
+  int32_t unit_queues;         // number of unit queues (1..8)
+  int32_t unit_affinity;       // 0: the wave's XCD picks its home queue (default); 1: wave number; 2: queue 0 (experiments)
   TfDev tf;
 };
 
@@ -139,13 +141,15 @@ struct clwh_ctx {
   size_t pix_slot_bytes = 0;
   clvr::HitRec *hits = nullptr;
   size_t hits_bytes = 0;
-  uint32_t *render_counters = nullptr;  // 4 x u32 on the device
+  uint32_t *render_counters = nullptr;  // kRenderCounters x u32 on the device
+  static constexpr size_t kRenderCounters = 32 * 9;
   uint32_t *fixups = nullptr;
   size_t fixups_bytes = 0;
   bool fixup_overflow_pending = false;
   // measured on MI355X (profiles/r01_tune_*.txt): a wave that runs its 64 samples to completion with
   // steps and events in separate wave-wide phases beats mid-flight refills (12.5 vs 7.6 Gsamples/s)
-  int32_t tune_step_min_lanes = 1, tune_refill_min_lanes = 64;
+  int32_t tune_step_min_lanes = 1;
+  int32_t tune_unit_group = 16, tune_unit_affinity = 0, tune_unit_queues = 8;
   uint32_t tune_bounce_max_blocks = 2048;
   bool primary_valid = false;
   uint32_t primary_n_hits = 0;

@@ -72,7 +72,9 @@ int clwh_ctx_create_on_stream(int device, void *hip_stream, clwh_ctx **out) {
   c->stream = (hipStream_t)hip_stream;
   c->own_stream = false;
   if (const char *e = std::getenv("CLWH_TUNE_STEP")) c->tune_step_min_lanes = std::max(1, std::min(64, std::atoi(e)));
-  if (const char *e = std::getenv("CLWH_TUNE_REFILL")) c->tune_refill_min_lanes = std::max(1, std::min(64, std::atoi(e)));
+  if (const char *e = std::getenv("CLWH_TUNE_AFFINITY")) c->tune_unit_affinity = std::atoi(e);
+  if (const char *e = std::getenv("CLWH_TUNE_QUEUES")) c->tune_unit_queues = std::max(1, std::min(8, std::atoi(e)));
+  if (const char *e = std::getenv("CLWH_TUNE_GROUP")) c->tune_unit_group = std::max(1, std::atoi(e));
   if (const char *e = std::getenv("CLWH_TUNE_BLOCKS")) c->tune_bounce_max_blocks = (uint32_t)std::max(1, std::atoi(e));
   *out = c;
   return CLWH_OK;
@@ -487,8 +489,10 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   }
   tf_to_dev(k->tf, a.tf);
   a.step_min_lanes = ctx->tune_step_min_lanes;
-  a.refill_min_lanes = ctx->tune_refill_min_lanes;
   a.bounce_max_blocks = ctx->tune_bounce_max_blocks;
+  a.unit_group = ctx->tune_unit_group;
+  a.unit_affinity = ctx->tune_unit_affinity;
+  a.unit_queues = ctx->tune_unit_queues;
 
   HIP_TRY(hipSetDevice(ctx->device));
   int rc = ensure_packed(ctx, d->volume, d->sdf, a.tf);
@@ -504,7 +508,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   if (rc != CLWH_OK) return rc;
   rc = grow(ctx, (void **)&ctx->hits, &ctx->hits_bytes, slots * sizeof(HitRec));
   if (rc != CLWH_OK) return rc;
-  if (!ctx->render_counters) HIP_TRY(hipMalloc((void **)&ctx->render_counters, 4 * sizeof(uint32_t)));
+  if (!ctx->render_counters) HIP_TRY(hipMalloc((void **)&ctx->render_counters, clwh_ctx::kRenderCounters * sizeof(uint32_t)));
   a.pix_slot = ctx->pix_slot;
   a.hits = ctx->hits;
   a.counters = ctx->render_counters;
@@ -523,7 +527,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   key.packed_generation = ctx->packed_generation;
   if (!ctx->primary_valid || std::memcmp(&key, &ctx->primary_key, sizeof key) != 0 || a.hit_index_out) {
     ctx->primary_valid = false;
-    HIP_TRY(hipMemsetAsync(ctx->render_counters, 0, 4 * sizeof(uint32_t), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->render_counters, 0, clwh_ctx::kRenderCounters * sizeof(uint32_t), ctx->stream));
     HIP_TRY(launch_primary(a, ctx->stream));
     uint32_t n_hits = 0;
     HIP_TRY(hipMemcpyAsync(&n_hits, ctx->render_counters, sizeof n_hits, hipMemcpyDeviceToHost, ctx->stream));
@@ -542,7 +546,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   if (rc != CLWH_OK) return rc;
   a.fixups = ctx->fixups;
   a.fixup_capacity = (uint32_t)std::min<size_t>(ctx->fixups_bytes / 128u, 0x7fffffffu);
-  HIP_TRY(hipMemsetAsync(ctx->render_counters + 1, 0, 3 * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->render_counters + 1, 0, (clwh_ctx::kRenderCounters - 1) * sizeof(uint32_t), ctx->stream));
   if (a.contrib_out) HIP_TRY(hipMemsetAsync(a.contrib_out, 0, npx * 16, ctx->stream));  // misses contribute nothing
   hipEvent_t ev_b = nullptr, ev_e = nullptr;
   if (ctx->timing) {

@@ -195,12 +195,20 @@ __device__ __forceinline__ void finish_item(const RenderArgs &a, int64_t entry, 
 // the reference's order.  Every sample is accumulated exactly once, by one of the two kernels.
 constexpr int kFixupDwords = 32;  // one record = 128 B: header[4] bv_before[3] n_pending[1] 2 x {P[3] factor dir[3]}
 
+#ifndef CLVR_BOUNCE_WAVES_PER_SIMD
+#define CLVR_BOUNCE_WAVES_PER_SIMD 6  // measured: 4/5/6/8 waves per SIMD -> 2.47/2.47/2.38/3.07 ms per 16-pass launch (8 spills)
+#endif
 template <bool USE_GRAD, int MODE>
-__global__ __launch_bounds__(256) void k_bounce(const RenderArgs a) {
+__global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(const RenderArgs a) {
   const VolumePacked vol = make_volume(a);
-  // counters: [0] hits, [1] queue head, [2] fix-up records, [3] fix-up overflow flag
-  const uint32_t total = a.n_hits * (uint32_t)a.n_seeds;
+  // counters: [0] hits, [2] fix-up records, [3] fix-up overflow flag, [32 * (q + 1)] head of unit queue q
+  const uint32_t n_chunks = (a.n_hits + 63u) >> 6;
   const unsigned lane = lane_id();
+  // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this wave runs on
+  unsigned home_queue = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+  if (a.unit_affinity == 1) home_queue = (blockIdx.x * 4u + (threadIdx.x >> 6)) & 7u;
+  if (a.unit_affinity == 2) home_queue = 0u;
+  unsigned queue_dry = 0u;  // bit q: queue q is known to be empty (lane 0's copy is the one that matters)
   int fix = -1;    // fix-up record of the lane's sample (-1: none, -2: dropped, the buffer overflowed)
   int npend = 0;   // pending environment terms written to it
 
@@ -222,19 +230,39 @@ __global__ __launch_bounds__(256) void k_bounce(const RenderArgs a) {
   bool exhausted = false;  // wave-uniform: the queue has no more items
 
   for (;;) {
-    // ---- refill idle lanes from the work queue (ballot + prefix compaction) ----------------------
-    const unsigned long long idle_mask = __ballot(st == ST_IDLE);
-    const int n_idle = __popcll(idle_mask);
-    if (!exhausted && n_idle > 0 && (n_idle >= a.refill_min_lanes || __ballot(st == ST_MARCH) == 0ull)) {
-      uint32_t base = 0u;
-      const int leader = __ffsll((long long)idle_mask) - 1;
-      if ((int)lane == leader) base = atomicAdd(&a.counters[1], (uint32_t)n_idle);
-      base = __shfl(base, leader);
-      if (base + (uint32_t)n_idle >= total) exhausted = true;
-      if (st == ST_IDLE) {
-        const uint32_t idx = base + prefix_count(idle_mask);
-        if (idx < total) {
-          const uint32_t s = idx / a.n_hits, h = idx - s * a.n_hits;
+    // ---- refill: an empty wave pulls one unit = (chunk of 64 consecutive hits, seed) -----------------
+    // Units are dealt to eight queues by chunk number; a wave serves the queue of the XCD it runs on
+    // first (so the 16 seeds of one chunk -- a thousand rays leaving the same few voxels -- meet in ONE
+    // L2) and steals from the other queues when its own is dry.  Placement only affects speed.
+    if (!exhausted && __ballot(st != ST_IDLE) == 0ull) {
+      uint32_t unit = 0xFFFFFFFFu;
+      if (lane == 0u) {
+        const unsigned NQ = (unsigned)a.unit_queues;
+        for (unsigned tries = 0; tries < NQ && unit == 0xFFFFFFFFu; ++tries) {
+          const unsigned q = (home_queue + tries) % NQ;
+          const uint32_t chunks_q = (n_chunks + NQ - 1u - q) / NQ;  // chunks c with c % NQ == q
+          if (chunks_q == 0u || ((queue_dry >> q) & 1u)) continue;
+          // every head sits on its own 128-byte line: same-address atomics serialise at one L2 channel
+          const uint32_t p = atomicAdd(&a.counters[32u * (q + 1u)], 1u);
+          if (p >= chunks_q * (uint32_t)a.n_seeds) queue_dry |= 1u << q;  // remembered: never asked again
+          if (p < chunks_q * (uint32_t)a.n_seeds) {
+            // queue order: groups of `unit_group` chunks, inside a group seed-major -- the 16 seeds of a chunk
+            // are `unit_group` units apart (their accumulation atomics do not collide) yet close enough to
+            // find each other's voxels still in L2
+            const uint32_t S = (uint32_t)a.n_seeds, G = (uint32_t)a.unit_group;
+            const uint32_t g = p / (G * S), r = p - g * (G * S);
+            const uint32_t in_group = min(G, chunks_q - g * G);  // the last group may be short
+            const uint32_t sd_i = r / in_group, ch = g * G + (r - sd_i * in_group);
+            unit = ((q + NQ * ch) << 4) | sd_i;
+          }
+        }
+      }
+      unit = __shfl(unit, 0);
+      if (unit == 0xFFFFFFFFu) {
+        exhausted = true;
+      } else {
+        const uint32_t h = (unit >> 4) * 64u + lane, s = unit & 15u;
+        if (h < a.n_hits) {
           fix = -1;
           npend = 0;
           const uint4 *src = reinterpret_cast<const uint4 *>(&a.hits[h]);
@@ -267,7 +295,7 @@ __global__ __launch_bounds__(256) void k_bounce(const RenderArgs a) {
     }
     if (__ballot(st != ST_IDLE) == 0ull) {
       if (exhausted) break;  // nothing in flight and nothing left to fetch
-      continue;              // every fetched item was refused its token: fetch again
+      continue;              // every sample of the unit was refused its token: fetch the next unit
     }
 
     // ---- step phase: MARCH lanes step until fewer than kStepPhaseMinLanes are still marching -----
