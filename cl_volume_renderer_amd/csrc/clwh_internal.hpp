@@ -19,6 +19,8 @@ struct TfRuleDev {
 struct TfDev {
   int32_t n;
   int32_t uses_gradient;
+  int32_t literal_gradient_taps;  // 1: always take the reference's 7-fetch step (test knob CLWH_TUNE_LITERAL_GRADIENT)
+  int32_t pad_;
   TfRuleDev rules[CLWH_TF_MAX_RULES];
 };
 
@@ -149,6 +151,7 @@ struct clwh_ctx {
   // measured on MI355X (profiles/r01_tune_*.txt): a wave that runs its 64 samples to completion with
   // steps and events in separate wave-wide phases beats mid-flight refills (12.5 vs 7.6 Gsamples/s)
   int32_t tune_step_min_lanes = 1;
+  int32_t tune_literal_gradient = 0;
   int32_t tune_unit_group = 16, tune_unit_affinity = 0, tune_unit_queues = 8;
   uint32_t tune_bounce_max_blocks = 2048;
   bool primary_valid = false;

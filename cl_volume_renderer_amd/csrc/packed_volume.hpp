@@ -5,10 +5,11 @@
 // addresses of consecutive steps coincide, so the shim keeps ONE 4-byte record per voxel
 //     bits  0..15  value   (int16, the volume texel)
 //     bits 16..23  sdf     (int8, the distance-field texel)
-//     bits 24..31  class   (1 + index of the first transfer-function rule the value satisfies, 0 = no
-//                           event; only when no rule reads `gradient`)
+//     bits 24..31  class   (1 + index of the first transfer-function rule the voxel satisfies, 0 = no
+//                           event; rules that read `gradient` use the gradient at the voxel's integer
+//                           position, see classify_step in render_device.hpp)
 // and one gather per step returns the classification of the new position AND the step length of the
-// next step.  When no rule reads `gradient` the march needs even less: a second array keeps ONE BYTE
+// next step.  The march needs even less: a second array keeps ONE BYTE
 // per voxel, bit 7 = "class != 0" (a Hit), bits 0-6 = max(sdf, 0) (the step is max(sdf, 0.5), so
 // negative distances all mean 0.5); the 4-byte record is only fetched at a Hit (colour) and for the
 // 6-tap normal.  Records are stored in 8x8x8 bricks made of eight 4x4x4 sub-bricks (256 B each, x
@@ -59,6 +60,17 @@ struct VolumePacked {
     const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
     if (!(gx >= 0.0f && gy >= 0.0f && gz >= 0.0f && gx < (float)X && gy < (float)Y && gz < (float)Z)) return 0u;
     return stepb[record_index((int)gx, (int)gy, (int)gz, NBX, NBY)];
+  }
+
+  // branch-free form of fetch_f for batches (the 6-tap normal): the load is always issued, from record 0
+  // when the texel is outside, and the result is masked afterwards -- so several taps can be in flight
+  // before the first wait instead of one full memory latency per tap
+  __device__ __forceinline__ uint32_t fetch_f_masked(float fx, float fy, float fz) const {
+    const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
+    const bool ok = gx >= 0.0f && gy >= 0.0f && gz >= 0.0f && gx < (float)X && gy < (float)Y && gz < (float)Z;
+    const size_t idx = record_index((int)(ok ? gx : 0.0f), (int)(ok ? gy : 0.0f), (int)(ok ? gz : 0.0f), NBX, NBY);
+    const uint32_t r = rec[idx];
+    return ok ? r : 0u;
   }
 
   __device__ __forceinline__ static int value_of(uint32_t r) { return (int)(int16_t)(r & 0xFFFFu); }

@@ -75,6 +75,20 @@ __device__ __forceinline__ f3 gradient_nn(const Vol &v, f3 p) {
   return f3{(float)dx, (float)dy, (float)dz};
 }
 
+// the same six taps on packed records, all loads issued before any is consumed
+__device__ __forceinline__ f3 gradient_nn(const VolumePacked &v, f3 p) {
+  const uint32_t xp = v.fetch_f_masked(p.x + 1.0f, p.y + 0.0f, p.z + 0.0f);
+  const uint32_t xm = v.fetch_f_masked(p.x - 1.0f, p.y - 0.0f, p.z - 0.0f);
+  const uint32_t yp = v.fetch_f_masked(p.x + 0.0f, p.y + 1.0f, p.z + 0.0f);
+  const uint32_t ym = v.fetch_f_masked(p.x - 0.0f, p.y - 1.0f, p.z - 0.0f);
+  const uint32_t zp = v.fetch_f_masked(p.x + 0.0f, p.y + 0.0f, p.z + 1.0f);
+  const uint32_t zm = v.fetch_f_masked(p.x - 0.0f, p.y - 0.0f, p.z - 1.0f);
+  const int dx = VolumePacked::value_of(xp) - VolumePacked::value_of(xm);
+  const int dy = VolumePacked::value_of(yp) - VolumePacked::value_of(ym);
+  const int dz = VolumePacked::value_of(zp) - VolumePacked::value_of(zm);
+  return f3{(float)dx, (float)dy, (float)dz};
+}
+
 // ------------------------------------------------------------------------------------------------
 // camera (utility_ray.cl:69-89) and box entry (utility_ray.cl:19-66, 92-97)
 __device__ __forceinline__ Ray generate_ray(f3 cam_origin, f3 cam_dir, int x, int y, int x_total, int y_total) {
@@ -191,36 +205,50 @@ __device__ __forceinline__ Ray march_to_next_event(const Vol &v, const TfDev &tf
 // (0 <= coord <= dim, which `!exited_volume` guarantees) trunc == floor, coord == dim reads the border
 // record 0 on both sides, and a NaN origin stays NaN whatever the step length.  Only the first SDF
 // read of a march is at an arbitrary origin and keeps the truncating int-coordinate read.
+// Transfer functions that read `gradient`: the class byte is baked from the gradient at the voxel's
+// INTEGER position.  The reference evaluates the six taps at the ray's float position p, i.e. at texels
+// floor(p +- 1); those are the voxel's own neighbours unless an addition rounds across an integer
+// (p.x = 255.99999 + 1 -> 257.0).  Such positions are detected exactly and take the literal 7-fetch route.
+__device__ __forceinline__ bool taps_are_voxel_neighbours(f3 p) {
+  return floorf(p.x + 1.0f) == floorf(p.x) + 1.0f && floorf(p.x - 1.0f) == floorf(p.x) - 1.0f &&
+         floorf(p.y + 1.0f) == floorf(p.y) + 1.0f && floorf(p.y - 1.0f) == floorf(p.y) - 1.0f &&
+         floorf(p.z + 1.0f) == floorf(p.z) + 1.0f && floorf(p.z - 1.0f) == floorf(p.z) - 1.0f;
+}
+
+// one march step's classification on the packed volume: returns true on a Hit (and updates `color`),
+// otherwise `next_sd` is the SDF value for the next step
+template <bool USE_GRAD>
+__device__ __forceinline__ bool classify_step(const VolumePacked &v, const TfDev &tf, f3 pos, uint32_t &color, int &next_sd) {
+  if (USE_GRAD && (tf.literal_gradient_taps || !taps_are_voxel_neighbours(pos))) {
+    const uint32_t r = v.fetch_f(pos.x, pos.y, pos.z);
+    const int gradient = (int)(short)f2i(length3(gradient_nn(v, pos)));
+    next_sd = VolumePacked::sdf_of(r) > 0 ? VolumePacked::sdf_of(r) : 0;
+    return tf_eval(tf, VolumePacked::value_of(r), gradient, color);
+  }
+  const unsigned q = v.step_f(pos.x, pos.y, pos.z);
+  next_sd = (int)(q & 0x7Fu);
+  if (!(q & 0x80u)) return false;
+  const unsigned cls = VolumePacked::class_of(v.fetch_f(pos.x, pos.y, pos.z));
+  const TfRuleDev &rule = tf.rules[cls - 1u];
+  if (rule.flags & TF_WRITES_COLOR) color = rule.color;
+  return true;
+}
+
+// The same march on the packed volume: one 1-byte gather per step.  The byte fetched at floor(new
+// origin) classifies the new position and carries the SDF value of the NEXT step: inside the volume
+// (0 <= coord <= dim, which `!exited_volume` guarantees) trunc == floor, coord == dim reads the border
+// on both sides, and a NaN origin stays NaN whatever the step length.  Only the first SDF read of a march
+// is at an arbitrary origin and keeps the truncating int-coordinate read.
 template <bool USE_GRAD>
 __device__ __forceinline__ Ray march_to_next_event(const VolumePacked &v, const TfDev &tf, Ray cur, int &event,
                                                    uint32_t &color) {
   int ev = EV_NONE;
-  if (USE_GRAD) {
-    int sd = v.sdf_at(f2i(cur.origin.x), f2i(cur.origin.y), f2i(cur.origin.z));
-    for (int i = 0; i < 70; ++i) {
-      const float step_size = cl_max((float)sd, 0.5f);
-      cur.origin = cur.origin + cur.direction * step_size;
-      if (exited_volume(v, cur.origin)) { ev = EV_EXIT; break; }
-      const uint32_t r = v.fetch_f(cur.origin.x, cur.origin.y, cur.origin.z);
-      const int gradient = (int)(short)f2i(length3(gradient_nn(v, cur.origin)));
-      if (tf_eval(tf, VolumePacked::value_of(r), gradient, color)) { ev = EV_HIT; break; }
-      sd = VolumePacked::sdf_of(r);
-    }
-  } else {
-    unsigned q = v.step_i(f2i(cur.origin.x), f2i(cur.origin.y), f2i(cur.origin.z));
-    for (int i = 0; i < 70; ++i) {
-      const float step_size = cl_max((float)(q & 0x7Fu), 0.5f);
-      cur.origin = cur.origin + cur.direction * step_size;
-      if (exited_volume(v, cur.origin)) { ev = EV_EXIT; break; }
-      q = v.step_f(cur.origin.x, cur.origin.y, cur.origin.z);
-      if (q & 0x80u) {
-        const unsigned cls = VolumePacked::class_of(v.fetch_f(cur.origin.x, cur.origin.y, cur.origin.z));
-        const TfRuleDev &rule = tf.rules[cls - 1u];
-        if (rule.flags & TF_WRITES_COLOR) color = rule.color;
-        ev = EV_HIT;
-        break;
-      }
-    }
+  int sd = (int)(v.step_i(f2i(cur.origin.x), f2i(cur.origin.y), f2i(cur.origin.z)) & 0x7Fu);
+  for (int i = 0; i < 70; ++i) {
+    const float step_size = cl_max((float)sd, 0.5f);
+    cur.origin = cur.origin + cur.direction * step_size;
+    if (exited_volume(v, cur.origin)) { ev = EV_EXIT; break; }
+    if (classify_step<USE_GRAD>(v, tf, cur.origin, color, sd)) { ev = EV_HIT; break; }
   }
   event = ev;
   return cur;

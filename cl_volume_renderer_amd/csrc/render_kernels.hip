@@ -70,14 +70,26 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
     const size_t i = ((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x;
     const int value = a.volume[i];
     const int sd = a.sdf[i];
+    int gradient = 0;
+    if (a.tf.uses_gradient) {
+      // |central differences| at the voxel's integer position, border 0 (utility_filter.cl:2-35), to short
+      auto at = [&](int px, int py, int pz) -> int {
+        if ((unsigned)px >= (unsigned)a.X || (unsigned)py >= (unsigned)a.Y || (unsigned)pz >= (unsigned)a.Z) return 0;
+        return a.volume[((size_t)pz * (size_t)a.Y + (size_t)py) * (size_t)a.X + (size_t)px];
+      };
+      const float gx = (float)(at(x + 1, y, z) - at(x - 1, y, z));
+      const float gy = (float)(at(x, y + 1, z) - at(x, y - 1, z));
+      const float gz = (float)(at(x, y, z + 1) - at(x, y, z - 1));
+      gradient = (int)(short)f2i(sqrtf((gx * gx + gy * gy) + gz * gz));
+    }
+    // class = 1 + index of the first matching rule; a terminal rule (`return (cond);`) ends the evaluation
     unsigned cls = 0u;
-    if (!a.tf.uses_gradient) {
-      // first matching rule wins; a terminal rule (`return (cond);`) ends the evaluation
-      for (int k = 0; k < a.tf.n; ++k) {
-        const TfRuleDev &rule = a.tf.rules[k];
-        if (value >= rule.v_lo && value <= rule.v_hi) { cls = (unsigned)k + 1u; break; }
-        if (rule.flags & TF_TERMINAL) break;
-      }
+    for (int k = 0; k < a.tf.n; ++k) {
+      const TfRuleDev &rule = a.tf.rules[k];
+      bool m = value >= rule.v_lo && value <= rule.v_hi;
+      if (rule.flags & TF_USE_GRADIENT) m = m && gradient >= rule.g_lo && gradient <= rule.g_hi;
+      if (m) { cls = (unsigned)k + 1u; break; }
+      if (rule.flags & TF_TERMINAL) break;
     }
     r = ((uint32_t)value & 0xFFFFu) | (((uint32_t)sd & 0xFFu) << 16) | (cls << 24);
     q = (uint8_t)((cls ? 0x80u : 0u) | (uint32_t)(sd > 0 ? sd : 0));
@@ -309,23 +321,8 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
             ev = EV_EXIT;
             st = ST_EVENT;
           } else {
-            bool is_hit;
             int next_sd;
-            if (USE_GRAD) {
-              const uint32_t r = vol.fetch_f(ray.origin.x, ray.origin.y, ray.origin.z);
-              const int gradient = (int)(short)f2i(length3(gradient_nn(vol, ray.origin)));
-              is_hit = tf_eval(a.tf, VolumePacked::value_of(r), gradient, color);
-              next_sd = VolumePacked::sdf_of(r);
-            } else {
-              const unsigned q = vol.step_f(ray.origin.x, ray.origin.y, ray.origin.z);
-              is_hit = (q & 0x80u) != 0u;
-              next_sd = (int)(q & 0x7Fu);
-              if (is_hit) {
-                const unsigned cls = VolumePacked::class_of(vol.fetch_f(ray.origin.x, ray.origin.y, ray.origin.z));
-                const TfRuleDev &rule = a.tf.rules[cls - 1u];
-                if (rule.flags & TF_WRITES_COLOR) color = rule.color;
-              }
-            }
+            const bool is_hit = classify_step<USE_GRAD>(vol, a.tf, ray.origin, color, next_sd);
             if (is_hit) {
               ev = EV_HIT;
               st = ST_EVENT;
@@ -451,8 +448,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
 
       if (st == ST_EVENT) {
         // start (or continue) a march: its first SDF read is at trunc(origin) (utility_ray.cl:148-150)
-        if (USE_GRAD) sd = vol.sdf_at(f2i(ray.origin.x), f2i(ray.origin.y), f2i(ray.origin.z));
-        else sd = (int)(vol.step_i(f2i(ray.origin.x), f2i(ray.origin.y), f2i(ray.origin.z)) & 0x7Fu);
+        sd = (int)(vol.step_i(f2i(ray.origin.x), f2i(ray.origin.y), f2i(ray.origin.z)) & 0x7Fu);
         steps_left = 70;
         st = ST_MARCH;
       }

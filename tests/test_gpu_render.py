@@ -245,3 +245,35 @@ def test_uncertified_env_lookups_are_fixed_up_exactly(gpu_ctx, orc):
     pos, d = look_at_centre(vol, [-20, 40, -20])
     st = _compare_passes(orc, gpu_ctx, vol, sdf, env, tf, (256, 192), pos, d, scene.glibc_rand(4))
     assert st["hits"] > 5000
+
+
+def test_gradient_tf_literal_taps_agree_with_baked_class(orc):
+    """TFs that read `gradient`: the march normally uses the class baked from the gradient at the voxel's
+    integer position and only falls back to the reference's literal 7-fetch step where a tap coordinate
+    rounds across an integer.  CLWH_TUNE_LITERAL_GRADIENT=1 forces the literal route everywhere: both
+    must give the oracle's bits."""
+    import os
+
+    tf = scene.tf_rect_source([(500.0, 1200.0, 150.0, 1500.0, (1.0, 0.8, 0.6, 0.5)),
+                               (20.0, 60.0, 30.0, 4000.0, (0.2, 0.9, 0.4, 0.8))])
+    vol, sdf, env, tf = small_scene(orc, 48, tf_source=tf)
+    pos, d = look_at_centre(vol, [-20, 40, -30])
+    o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (128, 128))
+    seeds = scene.glibc_rand(3)
+    for s in seeds:
+        o.render(pos, d, s)
+    assert (o.hit_index >= 0).sum() > 1000
+    for literal in ("1", None):
+        if literal:
+            os.environ["CLWH_TUNE_LITERAL_GRADIENT"] = literal
+        else:
+            os.environ.pop("CLWH_TUNE_LITERAL_GRADIENT", None)
+        ctx = ffi.Context(0)
+        g = GpuScene(ctx, vol, sdf, env, tf, (128, 128))
+        for s in seeds:
+            g.render(pos, d, s)
+        assert np.array_equal(g.cache.pull(), o.cache), "literal=%s" % literal
+        assert np.array_equal(g.hit_index.pull(), o.hit_index)
+        g.release()
+        ctx.destroy()
+    os.environ.pop("CLWH_TUNE_LITERAL_GRADIENT", None)
