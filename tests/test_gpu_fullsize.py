@@ -101,3 +101,31 @@ def test_job_level_properties_without_the_oracle(full):
     if cache[:, 3].max() < 256:
         assert cache[:, 3].sum() == 8 * int(hit.sum())
         assert np.array_equal(cache[:, :3].sum(axis=0), eight[:, :3].astype(np.int64).sum(axis=0))
+
+
+def test_large_volume_64bit_indexing(gpu_ctx, orc):
+    """1024^3: the voxel cache (8.6 GB) and the packed records (4 GiB + 1 GiB) need 64-bit byte offsets;
+    the reference itself cannot run here (its int index overflows above ~812^3, utility.cl:21, SURVEY
+    fact 9).  One pass against the oracle on the GPU-built SDF, plus the SDF's own properties."""
+    n = 1024
+    vol = scene.phantom(n)
+    env = scene.env_map(1024, 512)
+    tf = scene.tf_default_source()
+    w, h = 640, 360
+    g = GpuScene(gpu_ctx, vol, None, env, tf, (w, h))
+    n_layers = gpu_ctx.sdf_build(g.volume, tf, g.sdf)
+    sdf = g.sdf.pull()
+    assert n_layers % 2 == 1 and np.abs(sdf.astype(np.int16)).max() == 127
+    assert np.array_equal(sdf < 0, (vol >= 500) & (vol <= 1200))
+    pos, d = scene.default_camera(n)
+    o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (w, h), threads=min(16, len(os.sched_getaffinity(0))))
+    for s in scene.glibc_rand(2):
+        g.render(pos, d, s)
+        o.render(pos, d, s)
+    hits = o.hit_index[o.hit_index >= 0]
+    assert hits.size > 20000
+    assert (hits * 8 > 2 ** 32).any()          # byte offsets beyond 4 GiB are really exercised
+    assert np.array_equal(g.hit_index.pull(), o.hit_index)
+    assert np.array_equal(g.contrib.pull(), o.contrib)
+    assert np.array_equal(g.cache.pull(), o.cache)
+    g.release()
