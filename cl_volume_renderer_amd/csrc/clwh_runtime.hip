@@ -541,9 +541,9 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   a.n_hits = ctx->primary_n_hits;
 
   // ---- the pass: every (hit, seed) item
-  // fix-up records for environment lookups the fast path cannot certify: room for a quarter of the
-  // items, two orders of magnitude above the expected rate for env maps up to 32768 texels wide
-  const size_t fix_cap = std::max<size_t>(((size_t)a.n_hits * (size_t)a.n_seeds) / 4u, 4096u);
+  // fix-up records for environment lookups the fast path cannot certify: room for 1/16 of the items;
+  // the expected rate is 4e-6 x (0.16 w + 0.32 h) per lookup: 0.5 % at 4096x2048, 4 % at the 32768 limit
+  const size_t fix_cap = std::max<size_t>(((size_t)a.n_hits * (size_t)a.n_seeds) / 16u, 4096u);
   rc = grow(ctx, (void **)&ctx->fixups, &ctx->fixups_bytes, fix_cap * 128u);
   if (rc != CLWH_OK) return rc;
   a.fixups = ctx->fixups;
@@ -586,10 +586,10 @@ int clwh_accum_resolve(clwh_ctx *ctx, clwh_mem *accum_all, int32_t tile_world, u
   return CLWH_OK;
 }
 
-int clwh_ctx_invalidate_derived(clwh_ctx *ctx) {
+int clwh_ctx_invalidate_derived(clwh_ctx *ctx, int what) {
   if (!ctx) return CLWH_ERR_INVALID_VALUE;
-  ctx->packed_valid = false;
-  ctx->primary_valid = false;
+  if (what & CLWH_DERIVED_SCENE) ctx->packed_valid = false;
+  if (what & (CLWH_DERIVED_SCENE | CLWH_DERIVED_CAMERA)) ctx->primary_valid = false;
   return CLWH_OK;
 }
 

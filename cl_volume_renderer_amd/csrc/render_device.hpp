@@ -39,43 +39,8 @@ __device__ __forceinline__ bool tf_eval(const TfDev &tf, int value_in, int gradi
 }
 
 // ------------------------------------------------------------------------------------------------
-// volume accessors.  Integer images sampled with CLK_FILTER_LINEAR have no filtering: texel =
-// floor(coord); CLK_ADDRESS_CLAMP out-of-range (or NaN) reads return the border value 0.
-struct VolumeLinear {
-  const int16_t *__restrict__ vol;
-  const int8_t *__restrict__ sdf;
-  int X, Y, Z;
-
-  __device__ __forceinline__ size_t index(int x, int y, int z) const {
-    return ((size_t)z * (size_t)Y + (size_t)y) * (size_t)X + (size_t)x;
-  }
-  // read_imagei(volume, smp, float4)
-  __device__ __forceinline__ int value_at(float fx, float fy, float fz) const {
-    const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
-    if (!(gx >= 0.0f && gy >= 0.0f && gz >= 0.0f && gx < (float)X && gy < (float)Y && gz < (float)Z))
-      return 0;
-    return vol[index((int)gx, (int)gy, (int)gz)];
-  }
-  // read_imagei(sdf, smp, int4)
-  __device__ __forceinline__ int sdf_at(int x, int y, int z) const {
-    if ((unsigned)x >= (unsigned)X || (unsigned)y >= (unsigned)Y || (unsigned)z >= (unsigned)Z) return 0;
-    return sdf[index(x, y, z)];
-  }
-};
-
-// utility_filter.cl:2-35: central differences v(p+e_k) - v(p-e_k), no 1/2 factor
-template <class Vol>
-__device__ __forceinline__ f3 gradient_nn(const Vol &v, f3 p) {
-  int dx = v.value_at(p.x + 1.0f, p.y + 0.0f, p.z + 0.0f);
-  dx -= v.value_at(p.x - 1.0f, p.y - 0.0f, p.z - 0.0f);
-  int dy = v.value_at(p.x + 0.0f, p.y + 1.0f, p.z + 0.0f);
-  dy -= v.value_at(p.x - 0.0f, p.y - 1.0f, p.z - 0.0f);
-  int dz = v.value_at(p.x + 0.0f, p.y + 0.0f, p.z + 1.0f);
-  dz -= v.value_at(p.x - 0.0f, p.y - 0.0f, p.z - 1.0f);
-  return f3{(float)dx, (float)dy, (float)dz};
-}
-
-// the same six taps on packed records, all loads issued before any is consumed
+// utility_filter.cl:2-35: central differences v(p+e_k) - v(p-e_k), no 1/2 factor, border texel = 0;
+// the six taps read packed records, all loads issued before any is consumed
 __device__ __forceinline__ f3 gradient_nn(const VolumePacked &v, f3 p) {
   const uint32_t xp = v.fetch_f_masked(p.x + 1.0f, p.y + 0.0f, p.z + 0.0f);
   const uint32_t xm = v.fetch_f_masked(p.x - 1.0f, p.y - 0.0f, p.z - 0.0f);
@@ -176,35 +141,6 @@ __device__ __forceinline__ bool exited_volume(const Vol &v, f3 q) {
   return exited_max | exited_min;
 }
 
-template <bool USE_GRAD, class Vol>
-__device__ __forceinline__ int get_event_and_value(const Vol &v, const TfDev &tf, f3 position, uint32_t &color) {
-  if (exited_volume(v, position)) return EV_EXIT;
-  int gradient = 0;
-  if (USE_GRAD) gradient = (int)(short)f2i(length3(gradient_nn(v, position)));
-  const int value = v.value_at(position.x, position.y, position.z);
-  return tf_eval(tf, value, gradient, color) ? EV_HIT : EV_NONE;
-}
-
-template <bool USE_GRAD, class Vol>
-__device__ __forceinline__ Ray march_to_next_event(const Vol &v, const TfDev &tf, Ray cur, int &event, uint32_t &color) {
-  int ev = EV_NONE;
-  for (int i = 0; i < 70; ++i) {
-    // march(): step = max(sdf[trunc(origin)], 0.5)   (make_int truncates toward zero, utility.cl:13-16)
-    const float signed_distance = (float)v.sdf_at(f2i(cur.origin.x), f2i(cur.origin.y), f2i(cur.origin.z));
-    const float step_size = cl_max(signed_distance, 0.5f);
-    cur.origin = cur.origin + cur.direction * step_size;
-    ev = get_event_and_value<USE_GRAD>(v, tf, cur.origin, color);
-    if (ev != EV_NONE) break;
-  }
-  event = ev;
-  return cur;
-}
-
-// The same march on packed records: one gather per step.  The record fetched at floor(new origin)
-// classifies the new position and carries the SDF value of the NEXT step: inside the volume
-// (0 <= coord <= dim, which `!exited_volume` guarantees) trunc == floor, coord == dim reads the border
-// record 0 on both sides, and a NaN origin stays NaN whatever the step length.  Only the first SDF
-// read of a march is at an arbitrary origin and keeps the truncating int-coordinate read.
 // Transfer functions that read `gradient`: the class byte is baked from the gradient at the voxel's
 // INTEGER position.  The reference evaluates the six taps at the ray's float position p, i.e. at texels
 // floor(p +- 1); those are the voxel's own neighbours unless an addition rounds across an integer

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
             const uint32_t g = p / (G * S), r = p - g * (G * S);
             const uint32_t in_group = min(G, chunks_q - g * G);  // the last group may be short
             const uint32_t sd_i = r / in_group, ch = g * G + (r - sd_i * in_group);
-            unit = ((q + NQ * ch) << 4) | sd_i;
+            unit = ((q + NQ * ch) << 6) | sd_i;
           }
         }
       }
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
       if (unit == 0xFFFFFFFFu) {
         exhausted = true;
       } else {
-        const uint32_t h = (unit >> 4) * 64u + lane, s = unit & 15u;
+        const uint32_t h = (unit >> 6) * 64u + lane, s = unit & 63u;
         if (h < a.n_hits) {
           fix = -1;
           npend = 0;

@@ -16,6 +16,8 @@ OK = 0
 ELEM_S8, ELEM_S16, ELEM_S32, ELEM_U8, ELEM_U16, ELEM_U32, ELEM_F32 = range(7)
 ARG_MEM, ARG_I32, ARG_U32, ARG_F32, ARG_I64, ARG_U64, ARG_F64 = range(7)
 ACCUM_VOXEL_CACHE, ACCUM_IMAGE_SPACE = 0, 1
+DERIVED_SCENE, DERIVED_CAMERA = 1, 2
+MAX_SEEDS = 64
 TF_MAX_RULES = 16
 
 _ELEM_OF_DTYPE = {
@@ -65,7 +67,7 @@ class RenderDesc(C.Structure):
         ("tile_rank", C.c_int32), ("tile_world", C.c_int32),
         ("write_frame", C.c_int32),
         ("hit_index", C.c_void_p), ("contrib", C.c_void_p),
-        ("n_seeds", C.c_int32), ("seeds", C.c_int32 * 16),
+        ("n_seeds", C.c_int32), ("seeds", C.c_int32 * 64),
     ]
 
 
@@ -96,7 +98,7 @@ _PROTOTYPES = [
     ("clwh_accum_len", C.c_int64, [C.c_uint32, C.c_uint32, C.c_int32]),
     ("clwh_accum_resolve", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
-    ("clwh_ctx_invalidate_derived", C.c_int, [C.c_void_p]),
+    ("clwh_ctx_invalidate_derived", C.c_int, [C.c_void_p, C.c_int]),
     ("clwh_sdf_build", C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int32)]),
     ("clwh_buffer_reset", C.c_int, [C.c_void_p, C.c_void_p]),
     ("clwh_tf_parse", C.c_int, [C.c_char_p, C.POINTER(Tf)]),
@@ -288,8 +290,9 @@ class Context:
         _check(lib().clwh_accum_resolve(self.h, accum_all.h, tile_world, width, height, frame.h, env.h, p, d),
                "clwh_accum_resolve")
 
-    def invalidate_derived(self):
-        _check(lib().clwh_ctx_invalidate_derived(self.h), "clwh_ctx_invalidate_derived")
+    def invalidate_derived(self, scene=True, camera=True):
+        what = (DERIVED_SCENE if scene else 0) | (DERIVED_CAMERA if camera else 0)
+        _check(lib().clwh_ctx_invalidate_derived(self.h, what), "clwh_ctx_invalidate_derived")
 
     def finish(self):
         _check(lib().clwh_ctx_finish(self.h), "clwh_ctx_finish")

@@ -149,9 +149,9 @@ typedef struct clwh_render_desc {
   int32_t n_seeds;          /* > 0: render n_seeds passes (<= CLWH_MAX_SEEDS) in ONE launch, seeds[] below; the
                                result equals n_seeds consecutive single-seed calls (image-space mode always; voxel
                                cache mode while no voxel reaches the 256-token cap) */
-  int32_t seeds[16];
+  int32_t seeds[64];
 } clwh_render_desc;
-#define CLWH_MAX_SEEDS 16
+#define CLWH_MAX_SEEDS 64
 int clwh_render(clwh_kernel *render_kernel, const clwh_render_desc *desc);
 
 /* number of ushorts of a voxel cache for an X*Y*Z volume (the reference allocates X*Y*Z*4,
@@ -167,10 +167,12 @@ int64_t clwh_accum_len(uint32_t width, uint32_t height, int32_t tile_world);
 int clwh_accum_resolve(clwh_ctx *ctx, clwh_mem *accum_all_ranks, int32_t tile_world, uint32_t width,
                        uint32_t height, clwh_mem *frame_rgba8, clwh_mem *env, const float cam_pos[3],
                        const float cam_dir[3]);
-/* drop everything the context derived from its inputs (packed records, per-camera primary hits);
- * the next clwh_render rebuilds them.  Needed only when device memory was rewritten behind the
- * shim's back, or to time the rebuild. */
-int clwh_ctx_invalidate_derived(clwh_ctx *ctx);
+/* drop what the context derived from its inputs; the next clwh_render rebuilds it.  Needed only when
+ * device memory was rewritten behind the shim's back, or to time the rebuild.
+ *   CLWH_DERIVED_SCENE   packed records (function of volume, SDF, transfer function: flush-time data)
+ *   CLWH_DERIVED_CAMERA  primary hits (function of the camera and of the scene) */
+enum clwh_derived { CLWH_DERIVED_SCENE = 1, CLWH_DERIVED_CAMERA = 2 };
+int clwh_ctx_invalidate_derived(clwh_ctx *ctx, int what);
 
 /* clwh_sdf_build replaces the host loop of signed_distance_field::signed_distance_field
  * (app/signed_distance_field.cpp:7-35): base image + all propagation layers, no host round trip
