@@ -158,6 +158,8 @@ def main():
 
     for b in batches(seeds[: args.warmup]):
         render_passes(b)
+    tiles.gather_accum(accum, accum_all, world)  # untimed: RCCL sets its channels up on the first collective of a kind
+    ctx.accum_resolve(m_accum_all, world, W, H, d_frame, d_env, pos, cdir)
     accum.zero_()
     # the timed region starts like the first frame after a camera move: the per-camera primary hits are
     # rebuilt inside it (once); the packed records are flush-time data like the SDF and stay resident
