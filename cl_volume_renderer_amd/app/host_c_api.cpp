@@ -26,6 +26,7 @@ void clvr_host_destroy(clvr_host *h) { delete h; }
 // nrrd_loader::load_file + reference_volume + hdre_loader + env_map + image_set  (ui.cpp:182-194)
 void clvr_host_load(clvr_host *h, const short *voxels, unsigned X, unsigned Y, unsigned Z, const unsigned char *env_rgba,
                     unsigned env_w, unsigned env_h) {
+  h->rv.reset();  // release the old device images before allocating the new ones
   h->block.reset(new volume_block(std::vector<short>(voxels, voxels + (size_t)X * Y * Z), X, Y, Z, 1.f, 1.f, 1.f));
   h->rv.reset(new reference_volume(h->ctx, h->block.get()));
   h->rv->set_value_clip({-2000, 3000});
@@ -70,6 +71,14 @@ void clvr_host_pull_sdf(clvr_host *h, signed char *out) {
   auto &s = h->rend.distance_field().get_sdf_buffer();
   s.pull();
   std::memcpy(out, &s[0], s.size());
+}
+// reference_volume statistics (fetch_stats at construction) and clipping (apply_clip)
+void clvr_host_volume_stats(clvr_host *h, float out[4]) {
+  const Volume_Stats s = h->rv->get_volume_stats();
+  out[0] = s.min_v; out[1] = s.max_v; out[2] = s.min_g; out[3] = s.max_g;
+}
+void clvr_host_set_clipping(clvr_host *h, const unsigned lo[3], const unsigned hi[3]) {
+  h->rv->set_clipping({lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]});
 }
 int clvr_host_sdf_layers(clvr_host *h) { return h->rend.distance_field().layers(); }
 void clvr_host_camera_direction(float alpha, float beta, float out[3]) {

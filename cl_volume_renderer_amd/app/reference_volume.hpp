@@ -1,8 +1,8 @@
-// reference_volume.hpp -- owner of the volume image and of the size helpers every launch uses
-// (reference app/reference_volume.hpp, app/reference_volume.cpp:11-20, 89-112).
+// reference_volume.hpp -- owner of the volume image, its statistics and the size helpers every launch
+// uses (mirror of the reference's app/reference_volume.hpp / .cpp).
 // On the hot path: constructor (upload), get_volume_size*, get_volume_length, get_reference_volume.
-// The value range is computed on the host at upload; the gradient range, clipping and the bilateral
-// filter are pre-processing kernels ranked "next" in SURVEY 8f and not built yet.
+// Next to it: fetch_stats at construction, set_clipping (apply_clip).  The bilateral
+// `filter()` of the reference discards its result (app/reference_volume.cpp:77) and is not mirrored.
 #pragma once
 
 #include <array>
@@ -26,21 +26,26 @@ class reference_volume {
   reference_volume(clw_context &c, volume_block *b);
   void set_value_clip(std::array<int, 2> clip) { value_clip = clip; }
   void set_gradient_clip(std::array<int, 2> clip) { gradient_clip = clip; }
+  /// crop the volume to [min, max) -- rendering, SDF and cache then use the cropped copy
+  void set_clipping(std::array<size_t, 3> min, std::array<size_t, 3> max);
   std::array<int, 2> get_value_range() const;
   std::array<int, 2> get_gradient_range() const;
   const std::array<size_t, 3> &get_original_volume_size() const { return volume_size; }
-  const std::array<size_t, 3> &get_volume_size() const { return volume_size; }
+  const std::array<size_t, 3> &get_volume_size() const { return cropped_volume_size; }
   std::array<size_t, 3> get_volume_size_evenness(unsigned int l) const;
-  size_t get_volume_length() const { return volume_size[0] * volume_size[1] * volume_size[2]; }
-  const clw_image<short> &get_reference_volume() const { return original_volume; }
+  size_t get_volume_length() const { return cropped_volume_size[0] * cropped_volume_size[1] * cropped_volume_size[2]; }
+  const clw_image<short> &get_reference_volume() const { return is_cropped() ? cropped_volume : original_volume; }
   Volume_Stats get_volume_stats() const { return Volume_Stats(get_value_range(), get_gradient_range()); }
 
  private:
+  bool is_cropped() const { return cropped_volume.size() > 8; }  // the placeholder image has 8 voxels
   clw_context &ctx;
   std::array<size_t, 3> volume_size;
-  std::array<int, 2> value_range{0, 0};
-  std::array<int, 2> gradient_range{0, 4000};  // placeholder until fetch_stats is built
+  std::array<size_t, 3> cropped_volume_size;
   clw_image<short> original_volume;
+  clw_image<short> cropped_volume;
+  std::array<int, 2> value_range{0, 0};     // over the original volume
+  std::array<int, 2> gradient_range{0, 0};  // over the original volume
   std::array<int, 2> value_clip = {std::numeric_limits<int>::min(), std::numeric_limits<int>::max()};
   std::array<int, 2> gradient_clip = {std::numeric_limits<int>::min(), std::numeric_limits<int>::max()};
 };

@@ -130,6 +130,9 @@ hipError_t launch_sdf_base(const SdfArgs &a, hipStream_t s);
 hipError_t launch_sdf_base_front(const SdfArgs &a, uint8_t *flags, int32_t TX, int32_t TY, hipStream_t s);
 hipError_t launch_sdf_front(const SdfFrontArgs &a, hipStream_t s);
 hipError_t launch_sdf_layer(const SdfArgs &a, hipStream_t s);
+hipError_t launch_fetch_stats(const int16_t *vol, int X, int Y, int Z, int32_t *stats, hipStream_t s);
+hipError_t launch_apply_clip(const int16_t *src, int SX, int SY, int SZ, int16_t *dst, int DX, int DY, int DZ,
+                             const uint32_t *start, const uint32_t *len, hipStream_t s);
 
 }  // namespace clvr
 
@@ -200,7 +203,9 @@ enum clwh_kernel_id {
   CLWH_K_RENDER,
   CLWH_K_SDF_BASE,
   CLWH_K_SDF_LAYER,
-  CLWH_K_BUFFER_RESET
+  CLWH_K_BUFFER_RESET,
+  CLWH_K_FETCH_STATS,
+  CLWH_K_APPLY_CLIP
 };
 
 struct clwh_kernel {

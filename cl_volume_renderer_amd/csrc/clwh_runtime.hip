@@ -308,6 +308,8 @@ int clwh_kernel_get(clwh_ctx *ctx, const char *file, const char *entry, const ch
   else if (!std::strcmp(base, "signed_distance_field.cl") && !std::strcmp(entry, "create_signed_distance_field")) { id = CLWH_K_SDF_LAYER; }
   else if (!std::strcmp(base, "buffer_reset.cl") && !std::strcmp(entry, "buffer_reset")) { id = CLWH_K_BUFFER_RESET; }
   else if (!std::strcmp(base, "empty.cl") && !std::strcmp(entry, "empty")) { id = CLWH_K_EMPTY; }
+  else if (!std::strcmp(base, "reference_volume_figures.cl") && !std::strcmp(entry, "fetch_stats")) { id = CLWH_K_FETCH_STATS; }
+  else if (!std::strcmp(base, "reference_volume_clip.cl") && !std::strcmp(entry, "apply_clip")) { id = CLWH_K_APPLY_CLIP; }
   if (id < 0) return CLWH_ERR_UNKNOWN_KERNEL;
   clwh_kernel *k = new (std::nothrow) clwh_kernel();
   if (!k) return CLWH_ERR_OUT_OF_MEMORY;
@@ -759,6 +761,32 @@ int clwh_launch(clwh_kernel *k, const size_t global_in[3], const size_t local_in
       // buffer_reset(volume, buffer_volume)  buffer_reset.cl:3
       if (nargs != 2 || !is_mem(0) || !is_mem(1)) return CLWH_ERR_BAD_ARGS;
       return clwh_buffer_reset(ctx, args[1].v.mem);
+    }
+
+    case CLWH_K_FETCH_STATS: {
+      // fetch_stats(volume, int stats[5])  reference_volume_figures.cl:10
+      if (nargs != 2 || !is_mem(0) || !is_mem(1)) return CLWH_ERR_BAD_ARGS;
+      clwh_mem *v = args[0].v.mem, *st = args[1].v.mem;
+      if (!is_image(v, 3, 1, CLWH_ELEM_S16) || st->bytes < 4 * sizeof(int32_t)) return CLWH_ERR_BAD_ARGS;
+      if (v->dims[1] > 65535 || v->dims[2] > 65535) return CLWH_ERR_INVALID_VALUE;
+      HIP_TRY(launch_fetch_stats((const int16_t *)v->dptr, (int)v->dims[0], (int)v->dims[1], (int)v->dims[2],
+                                 (int32_t *)st->dptr, ctx->stream));
+      st->version++;
+      return CLWH_OK;
+    }
+
+    case CLWH_K_APPLY_CLIP: {
+      // apply_clip(original, clipped, uint start[3], uint len[4])  reference_volume_clip.cl:4
+      if (nargs != 4 || !is_mem(0) || !is_mem(1) || !is_mem(2) || !is_mem(3)) return CLWH_ERR_BAD_ARGS;
+      clwh_mem *src = args[0].v.mem, *dst = args[1].v.mem, *start = args[2].v.mem, *len = args[3].v.mem;
+      if (!is_image(src, 3, 1, CLWH_ELEM_S16) || !is_image(dst, 3, 1, CLWH_ELEM_S16) || start->bytes < 12 || len->bytes < 12)
+        return CLWH_ERR_BAD_ARGS;
+      if (dst->dims[1] > 65535 || dst->dims[2] > 65535) return CLWH_ERR_INVALID_VALUE;
+      HIP_TRY(launch_apply_clip((const int16_t *)src->dptr, (int)src->dims[0], (int)src->dims[1], (int)src->dims[2],
+                                (int16_t *)dst->dptr, (int)dst->dims[0], (int)dst->dims[1], (int)dst->dims[2],
+                                (const uint32_t *)start->dptr, (const uint32_t *)len->dptr, ctx->stream));
+      dst->version++;
+      return CLWH_OK;
     }
 
     case CLWH_K_SDF_BASE: {

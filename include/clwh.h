@@ -93,7 +93,8 @@ int clwh_mem_mark_dirty(clwh_mem *mem);
  * app/ui.cpp:160-168) into a rule table that becomes a launch-time parameter.
  * Known pairs: ("ray_marching.cl","render"), ("signed_distance_field.cl","create_base_image"),
  * ("signed_distance_field.cl","create_signed_distance_field"), ("buffer_reset.cl","buffer_reset"),
- * ("empty.cl","empty").
+ * ("empty.cl","empty"), and next to the hot path ("reference_volume_figures.cl","fetch_stats"),
+ * ("reference_volume_clip.cl","apply_clip").
  */
 int clwh_kernel_get(clwh_ctx *ctx, const char *file, const char *entry, const char *prepend,
                     clwh_kernel **out);

@@ -31,6 +31,8 @@ def _host():
     L.clvr_host_sdf_layers.restype = C.c_int
     L.clvr_host_sdf_layers.argtypes = [C.c_void_p]
     L.clvr_host_camera_direction.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float)]
+    L.clvr_host_volume_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    L.clvr_host_set_clipping.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
     return L
 
 
@@ -90,4 +92,47 @@ def test_renderer_frame_emitter_sequence_matches_oracle(orc):
     o.resolve(pos, d)
     frame = np.ctypeslib.as_array(C.cast(frame_ptr, C.POINTER(C.c_uint8)), shape=(1024, 2048, 4))
     assert np.array_equal(frame[:H, :W], o.frame[:H, :W])
+    L.clvr_host_destroy(h)
+
+
+@pytest.mark.gpu
+def test_reference_volume_stats_and_clipping(orc):
+    """reference_volume: fetch_stats at construction with the app's clip ranges (ui.cpp:187-188), then
+    set_clipping -> flush -> render on the cropped copy, against the oracle on the cropped numpy array."""
+    from oracle import orc_volume
+
+    L = _host()
+    n = 40
+    vol = scene.phantom(n)
+    env = scene.env_map(128, 64)
+    tf = scene.tf_default_source()
+    h = L.clvr_host_create()
+    L.clvr_host_load(h, vol.ctypes.data, n, n, n, env.ctypes.data, env.shape[1], env.shape[0])
+    st = (C.c_float * 4)()
+    L.clvr_host_volume_stats(h, st)
+    want = orc_volume.fetch_stats(vol)
+    assert list(st) == [max(-2000, want[0]), min(3000, want[1]), max(0, want[2]), min(4000, want[3])]
+
+    lo, hi = (4, 2, 6), (36, 34, 38)
+    L.clvr_host_set_clipping(h, (C.c_uint * 3)(*lo), (C.c_uint * 3)(*hi))
+    L.clvr_host_flush(h, tf.encode())
+    crop = np.ascontiguousarray(vol[lo[2]:hi[2], lo[1]:hi[1], lo[0]:hi[0]])
+    sdf = np.empty(L.clvr_host_sdf_len(h), np.int8)
+    L.clvr_host_pull_sdf(h, sdf.ctypes.data)
+    want_sdf, _, _ = orc.sdf_build(crop, orc.parse_tf(tf))
+    assert np.array_equal(sdf.reshape(crop.shape), want_sdf)
+
+    libc = C.CDLL("libc.so.6")
+    libc.srand(1)
+    pos = np.array([-16.0, 30.0, -14.0], np.float32)
+    look = np.array([0.8, 6.0], np.float32)
+    W, H = 96, 64
+    changed = C.c_int(0)
+    L.clvr_host_render_frame(h, pos.ctypes.data_as(C.POINTER(C.c_float)), look.ctypes.data_as(C.POINTER(C.c_float)),
+                             W, H, 1, C.byref(changed))
+    o = orc.Scene(crop, want_sdf, env, orc.parse_tf(tf), (2048, 1024), (W, H))
+    o.render(pos, scene.camera_direction(look[0], look[1]), scene.glibc_rand(1)[0])
+    cache = np.empty(L.clvr_host_cache_len(h), np.uint16)
+    L.clvr_host_pull_cache(h, cache.ctypes.data)
+    assert np.array_equal(cache, o.cache)
     L.clvr_host_destroy(h)
