@@ -1,6 +1,10 @@
 #include "renderer.hpp"
 
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
+#include <iostream>
+#include <set>
 
 #include <clwh.h>
 
@@ -60,11 +64,42 @@ void *renderer::render_frame(struct ui_state &state, bool &frame_changed) {
   return &frame[0];
 }
 
-// The 2-D (value, gradient) histogram texture of the transfer-function editor (reference :45-124) is a
-// UI widget outside the hot path; the symbol is kept so the application
-// links, and returns a transparent image of the requested size.
+// reference :45-124 -- the 2-D (value, |gradient|) histogram texture of the transfer-function editor:
+// bin the volume, quantise the counts on the host so that small counts stay distinguishable, rank the
+// distinct counts, colour each bin by its rank.  (The reference declares render_tf(width, height) and
+// defines render_tf(height, width); both call sites pass 500 x 500.)
 void *renderer::render_tf(const unsigned int height, const unsigned int width) {
-  const unsigned int w = width < 2 ? 2 : width, h = height < 1 ? 1 : height;
-  tfframe = clw_image<unsigned char, 4>(ctx, std::vector<unsigned char>((size_t)w * h * 4, 0), {w, h, 1});
+  tfframe = clw_image<unsigned char, 4>(ctx, std::vector<unsigned char>((size_t)height * width * 4), {width, height, 1});
+
+  clw_vector<unsigned int> bins(ctx, std::vector<unsigned int>((size_t)width * height, 0));
+  bins.push();
+  const Volume_Stats stats = volume->get_volume_stats();
+  clw_function sort_values(ctx, "histogram.cl", "tf_sort_values");
+  sort_values.execute(volume->get_volume_size_evenness(8), {4, 4, 4}, volume->get_reference_volume(), bins, width, height,
+                      stats.min_v, stats.max_v, stats.min_g, stats.max_g);
+  bins.pull();
+
+  // round every count down to its two leading decimal digits and collect the distinct results
+  std::set<int> distinct;
+  for (size_t i = 0; i < bins.size(); ++i) {
+    const int value = (int)bins[i];
+    if (value == 0) continue;
+    const int unit = std::max((int)std::pow(10, std::floor(std::log10(value)) - 1), 1);
+    const int corrected = (int)(std::floor(value / unit) * unit);
+    bins[i] = (unsigned int)corrected;
+    distinct.insert(corrected);
+  }
+  bins.push();
+
+  if (distinct.empty()) {
+    std::cout << "Warning, histogram does not contain non-zero entries.\n";
+  } else {
+    clw_vector<int> ranks(ctx, std::vector<int>(distinct.begin(), distinct.end()));
+    ranks.push();
+    clw_function flush_colors(ctx, "histogram.cl", "tf_flush_color_frame");
+    flush_colors.execute({evenness((unsigned)tfframe.get_dimensions()[0], 16), evenness((unsigned)tfframe.get_dimensions()[1], 16), 1},
+                         {16, 16, 1}, tfframe, bins, ranks, (int)ranks.size());
+  }
+  tfframe.pull();
   return &tfframe[0];
 }

@@ -131,6 +131,10 @@ hipError_t launch_sdf_base_front(const SdfArgs &a, uint8_t *flags, int32_t TX, i
 hipError_t launch_sdf_front(const SdfFrontArgs &a, hipStream_t s);
 hipError_t launch_sdf_layer(const SdfArgs &a, hipStream_t s);
 hipError_t launch_fetch_stats(const int16_t *vol, int X, int Y, int Z, int32_t *stats, hipStream_t s);
+hipError_t launch_tf_sort_values(const int16_t *vol, int X, int Y, int Z, uint32_t *frame, int width, int height,
+                                 float min_v, float max_v, float min_g, float max_g, hipStream_t s);
+hipError_t launch_tf_flush_color_frame(uint32_t *color_frame, int fw, int fh, const int32_t *frame, const int32_t *lookup,
+                                       int lookup_len, hipStream_t s);
 hipError_t launch_apply_clip(const int16_t *src, int SX, int SY, int SZ, int16_t *dst, int DX, int DY, int DZ,
                              const uint32_t *start, const uint32_t *len, hipStream_t s);
 
@@ -205,7 +209,9 @@ enum clwh_kernel_id {
   CLWH_K_SDF_LAYER,
   CLWH_K_BUFFER_RESET,
   CLWH_K_FETCH_STATS,
-  CLWH_K_APPLY_CLIP
+  CLWH_K_APPLY_CLIP,
+  CLWH_K_TF_SORT_VALUES,
+  CLWH_K_TF_FLUSH_COLOR_FRAME
 };
 
 struct clwh_kernel {

@@ -310,6 +310,8 @@ int clwh_kernel_get(clwh_ctx *ctx, const char *file, const char *entry, const ch
   else if (!std::strcmp(base, "empty.cl") && !std::strcmp(entry, "empty")) { id = CLWH_K_EMPTY; }
   else if (!std::strcmp(base, "reference_volume_figures.cl") && !std::strcmp(entry, "fetch_stats")) { id = CLWH_K_FETCH_STATS; }
   else if (!std::strcmp(base, "reference_volume_clip.cl") && !std::strcmp(entry, "apply_clip")) { id = CLWH_K_APPLY_CLIP; }
+  else if (!std::strcmp(base, "histogram.cl") && !std::strcmp(entry, "tf_sort_values")) { id = CLWH_K_TF_SORT_VALUES; }
+  else if (!std::strcmp(base, "histogram.cl") && !std::strcmp(entry, "tf_flush_color_frame")) { id = CLWH_K_TF_FLUSH_COLOR_FRAME; }
   if (id < 0) return CLWH_ERR_UNKNOWN_KERNEL;
   clwh_kernel *k = new (std::nothrow) clwh_kernel();
   if (!k) return CLWH_ERR_OUT_OF_MEMORY;
@@ -772,6 +774,37 @@ int clwh_launch(clwh_kernel *k, const size_t global_in[3], const size_t local_in
       HIP_TRY(launch_fetch_stats((const int16_t *)v->dptr, (int)v->dims[0], (int)v->dims[1], (int)v->dims[2],
                                  (int32_t *)st->dptr, ctx->stream));
       st->version++;
+      return CLWH_OK;
+    }
+
+    case CLWH_K_TF_SORT_VALUES: {
+      // tf_sort_values(volume, uint* frame, int width, int height, float min_v, max_v, min_g, max_g)  histogram.cl:4
+      if (nargs != 8 || !is_mem(0) || !is_mem(1)) return CLWH_ERR_BAD_ARGS;
+      clwh_mem *v = args[0].v.mem, *fr = args[1].v.mem;
+      int32_t w, h;
+      float f[4];
+      if (!as_i32(2, w) || !as_i32(3, h)) return CLWH_ERR_BAD_ARGS;
+      for (int q = 0; q < 4; ++q)
+        if (!as_f32(4 + q, f[q])) return CLWH_ERR_BAD_ARGS;
+      if (!is_image(v, 3, 1, CLWH_ELEM_S16) || w <= 0 || h <= 0 || fr->bytes < (size_t)w * (size_t)h * 4u) return CLWH_ERR_BAD_ARGS;
+      if (v->dims[1] > 65535 || v->dims[2] > 65535) return CLWH_ERR_INVALID_VALUE;
+      HIP_TRY(launch_tf_sort_values((const int16_t *)v->dptr, (int)v->dims[0], (int)v->dims[1], (int)v->dims[2],
+                                    (uint32_t *)fr->dptr, w, h, f[0], f[1], f[2], f[3], ctx->stream));
+      fr->version++;
+      return CLWH_OK;
+    }
+
+    case CLWH_K_TF_FLUSH_COLOR_FRAME: {
+      // tf_flush_color_frame(image2d color_frame, int* frame, int* lookup, int lookup_len)  histogram.cl:34
+      if (nargs != 4 || !is_mem(0) || !is_mem(1) || !is_mem(2)) return CLWH_ERR_BAD_ARGS;
+      clwh_mem *cf = args[0].v.mem, *fr = args[1].v.mem, *lk = args[2].v.mem;
+      int32_t len;
+      if (!as_i32(3, len) || !is_image(cf, 2, 4, CLWH_ELEM_U8)) return CLWH_ERR_BAD_ARGS;
+      const size_t fw = cf->dims[0], fh = cf->dims[1];
+      if (fr->bytes < fw * fh * 4u || len < 0 || lk->bytes < (size_t)len * 4u) return CLWH_ERR_SIZE_MISMATCH;
+      HIP_TRY(launch_tf_flush_color_frame((uint32_t *)cf->dptr, (int)fw, (int)fh, (const int32_t *)fr->dptr,
+                                          (const int32_t *)lk->dptr, len, ctx->stream));
+      cf->version++;
       return CLWH_OK;
     }
 

@@ -66,6 +66,90 @@ __global__ __launch_bounds__(256) void k_apply_clip(const int16_t *__restrict__ 
   dst[((size_t)z * (size_t)DY + (size_t)y) * (size_t)DX + (size_t)x] = v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// tf_sort_values  opencl_kernels/histogram.cl:4-32: 2-D histogram over (value, |gradient|) for the
+// transfer-function editor.  The reference does one global atomic per voxel; CT data puts most voxels
+// into a handful of bins, so here a thread walks 16 consecutive voxels merging equal bins, and a wave
+// merges equal bins across its lanes before anything reaches memory.  Bins outside the width x height
+// frame (value == max_value rounds to column `width`; values below min_value go negative -- both write
+// out of bounds in the reference) are dropped.
+__global__ __launch_bounds__(256) void k_tf_sort_values(const int16_t *__restrict__ vol, int X, int Y, int Z, uint32_t *frame,
+                                                        int width, int height, float min_value, float max_value,
+                                                        float min_gradient, float max_gradient) {
+  constexpr int kRun = 16;
+  const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * kRun;
+  const int y = blockIdx.y, z = blockIdx.z;
+  auto at = [&](int px, int py, int pz) -> int {
+    if ((unsigned)px >= (unsigned)X || (unsigned)py >= (unsigned)Y || (unsigned)pz >= (unsigned)Z) return 0;
+    return vol[((size_t)pz * (size_t)Y + (size_t)py) * (size_t)X + (size_t)px];
+  };
+  const float value_range = max_value - min_value;
+  const float gradient_range = max_gradient - min_gradient;
+  int run_bin = -1;
+  uint32_t run_count = 0u;
+  auto flush = [&]() {
+    // merge equal bins across the wave: one atomic per distinct bin
+    int bin = run_count ? run_bin : -1;
+    unsigned long long todo = __ballot(bin >= 0);
+    while (todo != 0ull) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int b = __shfl(bin, leader);
+      const unsigned long long same = __ballot(bin == b);
+      uint32_t c = (bin == b) ? run_count : 0u;
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+      if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&frame[b], c);
+      todo &= ~same;
+    }
+    run_bin = -1;
+    run_count = 0u;
+  };
+  for (int k = 0; k < kRun; ++k) {
+    const int x = x0 + k;
+    int bin = -1;
+    if (x < X) {
+      const int ref_value = at(x, y, z);
+      const float gx = (float)(at(x + 1, y, z) - at(x - 1, y, z));
+      const float gy = (float)(at(x, y + 1, z) - at(x, y - 1, z));
+      const float gz = (float)(at(x, y, z + 1) - at(x, y, z - 1));
+      const float grad_length = sqrtf((gx * gx + gy * gy) + gz * gz);
+      if (!(grad_length > max_gradient) && !((float)ref_value > max_value)) {
+        const int px = f2i(roundf((((float)ref_value - min_value) / value_range) * (float)width));
+        const int py = f2i(roundf(((grad_length - min_gradient) / gradient_range) * (float)height));
+        if (px >= 0 && px < width && py >= 0 && py < height) bin = px * height + py;
+      }
+    }
+    // the wave must reach flush() together: flush when any lane's bin changes
+    const bool changes = bin != run_bin && run_count != 0u;
+    if (__ballot(changes) != 0ull) flush();
+    if (bin >= 0) {
+      run_bin = bin;
+      run_count += 1u;
+    }
+  }
+  flush();
+}
+
+// tf_flush_color_frame  opencl_kernels/histogram.cl:34-69: bin count -> rank among the distinct counts ->
+// grey level 20..255 (0 for empty bins), rows flipped
+__global__ __launch_bounds__(256) void k_tf_flush_color_frame(uint32_t *color_frame, int fw, int fh, const int32_t *frame,
+                                                              const int32_t *lookup, int lookup_len) {
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x >= fw || y >= fh) return;
+  const int value = frame[x * fh + (fh - y - 1)];
+  // `lookup` is sorted ascending (a std::set on the host): binary search instead of the linear scan
+  int lo = 0, hi = lookup_len - 1, local_value = -1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const int v = lookup[mid];
+    if (v == value) { local_value = mid; break; }
+    if (v < value) lo = mid + 1; else hi = mid - 1;
+  }
+  int result = 0;
+  if (local_value > -1) result = (int)(20.0f + (((float)local_value) / (float)lookup_len) * (255.0f - 20.0f));
+  const uint32_t c = (uint32_t)min(max(result, 0), 255);  // write_imagei on an UNSIGNED_INT8 image saturates
+  color_frame[(size_t)y * fw + x] = c | (c << 8) | (c << 16) | (255u << 24);
+}
+
 static unsigned row_block(int X) { return X <= 64 ? 64u : (X <= 128 ? 128u : 256u); }
 
 hipError_t launch_fetch_stats(const int16_t *vol, int X, int Y, int Z, int32_t *stats, hipStream_t s) {
@@ -79,6 +163,21 @@ hipError_t launch_apply_clip(const int16_t *src, int SX, int SY, int SZ, int16_t
   const unsigned b = row_block(DX);
   hipLaunchKernelGGL(k_apply_clip, dim3(((unsigned)DX + b - 1u) / b, (unsigned)DY, (unsigned)DZ), dim3(b), 0, s, src, SX, SY,
                      SZ, dst, DX, DY, DZ, start, len);
+  return hipGetLastError();
+}
+
+hipError_t launch_tf_sort_values(const int16_t *vol, int X, int Y, int Z, uint32_t *frame, int width, int height,
+                                 float min_v, float max_v, float min_g, float max_g, hipStream_t s) {
+  const unsigned per_block = 64u * 16u;  // one wave per block: the flush is a wave-wide rendezvous
+  hipLaunchKernelGGL(k_tf_sort_values, dim3(((unsigned)X + per_block - 1u) / per_block, (unsigned)Y, (unsigned)Z), dim3(64), 0, s,
+                     vol, X, Y, Z, frame, width, height, min_v, max_v, min_g, max_g);
+  return hipGetLastError();
+}
+
+hipError_t launch_tf_flush_color_frame(uint32_t *color_frame, int fw, int fh, const int32_t *frame, const int32_t *lookup,
+                                       int lookup_len, hipStream_t s) {
+  hipLaunchKernelGGL(k_tf_flush_color_frame, dim3((unsigned)(fw + 15) / 16u, (unsigned)(fh + 15) / 16u), dim3(256), 0, s,
+                     color_frame, fw, fh, frame, lookup, lookup_len);
   return hipGetLastError();
 }
 

@@ -51,3 +51,57 @@ def apply_clip(vol: np.ndarray, start, length) -> np.ndarray:
     if x1 > start[0] and y1 > start[1] and z1 > start[2]:
         out[: z1 - start[2], : y1 - start[1], : x1 - start[0]] = vol[start[2]:z1, start[1]:y1, start[0]:x1]
     return out
+
+
+def gradient_length_f32(vol: np.ndarray) -> np.ndarray:
+    v = vol.astype(np.int32)
+    gx = (_shift(v, 2, 1) - _shift(v, 2, -1)).astype(np.float32)
+    gy = (_shift(v, 1, 1) - _shift(v, 1, -1)).astype(np.float32)
+    gz = (_shift(v, 0, 1) - _shift(v, 0, -1)).astype(np.float32)
+    return np.sqrt((gx * gx + gy * gy) + gz * gz, dtype=np.float32)
+
+
+def _round_half_away(x: np.ndarray) -> np.ndarray:
+    return np.where(x >= 0, np.floor(x + np.float32(0.5)), np.ceil(x - np.float32(0.5))).astype(np.float32)
+
+
+def tf_sort_values(vol, width, height, min_v, max_v, min_g, max_g) -> np.ndarray:
+    """opencl_kernels/histogram.cl:4-32; bins outside the frame are dropped (the reference writes out of
+    bounds for them).  Returns frame[width*height] indexed x*height + y."""
+    f32 = np.float32
+    g = gradient_length_f32(vol)
+    v = vol.astype(np.float32)
+    keep = ~(g > f32(max_g)) & ~(v > f32(max_v))
+    px = _round_half_away(((v - f32(min_v)) / (f32(max_v) - f32(min_v))) * f32(width)).astype(np.int64)
+    py = _round_half_away(((g - f32(min_g)) / (f32(max_g) - f32(min_g))) * f32(height)).astype(np.int64)
+    keep &= (px >= 0) & (px < width) & (py >= 0) & (py < height)
+    frame = np.zeros(width * height, dtype=np.uint32)
+    np.add.at(frame, (px[keep] * height + py[keep]).ravel(), 1)
+    return frame
+
+
+def render_tf(vol, width, height, min_v, max_v, min_g, max_g) -> np.ndarray:
+    """app/renderer.cpp:45-124 end to end: RGBA8 [height][width][4]."""
+    import math
+
+    frame = tf_sort_values(vol, width, height, min_v, max_v, min_g, max_g).astype(np.int64)
+    distinct = set()
+    for i in np.nonzero(frame)[0]:
+        value = int(frame[i])
+        unit = max(int(math.pow(10, math.floor(math.log10(value)) - 1)), 1)
+        corrected = int(math.floor(value // unit) * unit)
+        frame[i] = corrected
+        distinct.add(corrected)
+    lookup = sorted(distinct)
+    rank = {v: i for i, v in enumerate(lookup)}
+    out = np.zeros((height, width, 4), dtype=np.uint8)
+    out[..., 3] = 255
+    if not lookup:
+        return out * 0  # the kernel is not launched: the image keeps its zeros
+    fr = frame.reshape(width, height)
+    for y in range(height):
+        col = fr[:, height - y - 1]
+        for x in np.nonzero(col)[0]:
+            r = np.float32(20.0) + (np.float32(rank[int(col[x])]) / np.float32(len(lookup))) * np.float32(235.0)
+            out[y, x, :3] = min(max(int(r), 0), 255)
+    return out

@@ -33,6 +33,8 @@ def _host():
     L.clvr_host_camera_direction.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float)]
     L.clvr_host_volume_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.clvr_host_set_clipping.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    L.clvr_host_render_tf.restype = C.c_void_p
+    L.clvr_host_render_tf.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
     return L
 
 
@@ -135,4 +137,26 @@ def test_reference_volume_stats_and_clipping(orc):
     cache = np.empty(L.clvr_host_cache_len(h), np.uint16)
     L.clvr_host_pull_cache(h, cache.ctypes.data)
     assert np.array_equal(cache, o.cache)
+    L.clvr_host_destroy(h)
+
+
+@pytest.mark.gpu
+def test_render_tf_histogram_texture(orc):
+    """frame_emitter::render_tf (ui.cpp:151-158 -> renderer.cpp:45-124): the 2-D histogram texture."""
+    from oracle import orc_volume
+
+    L = _host()
+    n = 40
+    vol = scene.phantom(n)
+    env = scene.env_map(64, 32)
+    h = L.clvr_host_create()
+    L.clvr_host_load(h, vol.ctypes.data, n, n, n, env.ctypes.data, env.shape[1], env.shape[0])
+    st = (C.c_float * 4)()
+    L.clvr_host_volume_stats(h, st)
+    w = hgt = 100
+    ptr = L.clvr_host_render_tf(h, w, hgt)
+    got = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(hgt, w, 4)).copy()
+    want = orc_volume.render_tf(vol, w, hgt, st[0], st[1], st[2], st[3])
+    assert (want[..., 0] > 0).sum() > 20
+    assert np.array_equal(got, want)
     L.clvr_host_destroy(h)
