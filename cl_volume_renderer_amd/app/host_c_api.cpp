@@ -6,6 +6,7 @@
 #include <memory>
 #include <string>
 
+#include "nrrd_loader.hpp"
 #include "renderer.hpp"
 
 struct clvr_host {
@@ -82,6 +83,16 @@ void clvr_host_set_clipping(clvr_host *h, const unsigned lo[3], const unsigned h
 }
 // _create_tf (ui.cpp:151-158): the transfer-function editor's histogram texture, RGBA8, width x height
 const void *clvr_host_render_tf(clvr_host *h, unsigned width, unsigned height) { return h->rend.render_tf(width, height); }
+// nrrd_loader::load_file probe (no device involved): dims, voxel count, sum of all voxels
+long long clvr_host_nrrd_probe(const char *path, unsigned dims[3], long long *checksum) {
+  nrrd_loader loader;
+  volume_block b = loader.load_file(path);
+  dims[0] = b.m_voxel_count_x; dims[1] = b.m_voxel_count_y; dims[2] = b.m_voxel_count_z;
+  long long sum = 0;
+  for (short v : b.m_voxels) sum += v;
+  *checksum = sum;
+  return (long long)b.m_voxels.size();
+}
 int clvr_host_sdf_layers(clvr_host *h) { return h->rend.distance_field().layers(); }
 void clvr_host_camera_direction(float alpha, float beta, float out[3]) {
   Position3D v(alpha, beta, 0.0, {1.0, 0.0, 0.0});

@@ -27,7 +27,8 @@ FLAGS = [
 
 HOST_LIB = os.path.join(HERE, "libclvr_host.so")
 APP = os.path.join(HERE, "app")
-HOST_SOURCES = ["renderer.cpp", "reference_volume.cpp", "signed_distance_field.cpp", "host_c_api.cpp"]
+HOST_SOURCES = ["renderer.cpp", "reference_volume.cpp", "signed_distance_field.cpp", "nrrd_loader.cpp", "host_c_api.cpp"]
+HOST_PROGRAMS = {"sdf_test": "sdf_test_main.cpp", "sdf_benchmark": "sdf_benchmark_main.cpp"}
 CXX = os.environ.get("CXX", "g++")
 
 
@@ -40,10 +41,17 @@ def build_host(force: bool = False, verbose: bool = False) -> str:
         return HOST_LIB
     cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", APP]
     cmd += [os.path.join(APP, s) for s in HOST_SOURCES]
-    cmd += ["-o", HOST_LIB, "-L", HERE, "-lclwhip", "-Wl,-rpath,$ORIGIN"]
+    cmd += ["-o", HOST_LIB, "-L", HERE, "-lclwhip", "-lz", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    # the reference's two headless programs over the same classes (tests/sdf/sdf_test.cpp, app/sdf_benchmark.cpp)
+    for name, src in HOST_PROGRAMS.items():
+        cmd = [CXX, "-O2", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", APP, os.path.join(APP, src),
+               "-o", os.path.join(HERE, name), "-L", HERE, "-lclvr_host", "-lclwhip", "-lz", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
     return HOST_LIB
 
 

@@ -160,3 +160,39 @@ def test_render_tf_histogram_texture(orc):
     assert (want[..., 0] > 0).sum() > 20
     assert np.array_equal(got, want)
     L.clvr_host_destroy(h)
+
+
+def test_nrrd_loader_reads_the_reference_test_block(tmp_path):
+    """app/nrrd_loader.cpp mirror (CPU only): gzip payload of the reference's testdata.nrrd and a raw file
+    written by this project's writer decode to the same voxels as the Python reader."""
+    L = _host()
+    L.clvr_host_nrrd_probe.restype = C.c_longlong
+    L.clvr_host_nrrd_probe.argtypes = [C.c_char_p, C.POINTER(C.c_uint), C.POINTER(C.c_longlong)]
+    dims = (C.c_uint * 3)()
+    checksum = C.c_longlong(0)
+    path = os.path.join(ROOT, "tests", "golden", "sdf_testdata.nrrd")
+    n = L.clvr_host_nrrd_probe(path.encode(), dims, C.byref(checksum))
+    vol = scene.read_nrrd(path)
+    assert list(dims) == [38, 35, 38] and n == 50540
+    assert checksum.value == int(vol.astype(np.int64).sum()) == 26559114  # SURVEY 8c
+    raw = str(tmp_path / "raw.nrrd")
+    v2 = scene.phantom(20, dims=(20, 12, 9))
+    scene.write_nrrd(raw, v2, use_gzip=False)
+    assert L.clvr_host_nrrd_probe(raw.encode(), dims, C.byref(checksum)) == v2.size
+    assert list(dims) == [20, 12, 9] and checksum.value == int(v2.astype(np.int64).sum())
+    gz = str(tmp_path / "gz.nrrd")
+    scene.write_nrrd(gz, v2, use_gzip=True)
+    assert L.clvr_host_nrrd_probe(gz.encode(), dims, C.byref(checksum)) == v2.size
+    assert checksum.value == int(v2.astype(np.int64).sum())
+
+
+@pytest.mark.gpu
+def test_reference_sdf_test_program():
+    """the reference's only test, tests/sdf/sdf_test.cpp, as a program over this project's headers"""
+    import subprocess
+
+    exe = os.path.join(ROOT, "cl_volume_renderer_amd", "sdf_test")
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "sdf_testdata.nrrd"),
+                          os.path.join(ROOT, "tests", "golden", "sdf_values.x")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "EVERYTHING FINE" in out.stdout and "13 layers" in out.stdout
