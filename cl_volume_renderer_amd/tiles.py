@@ -59,5 +59,11 @@ def gather_accum(accum, accum_all, world: int):
         return accum_all
     import torch.distributed as dist
 
-    dist.all_gather_into_tensor(accum_all, accum)
+    if dist.get_backend() == "nccl" or not accum.is_cuda:
+        dist.all_gather_into_tensor(accum_all, accum)
+    else:
+        # rehearsal without RCCL (gloo): stage through the host
+        host_all = accum_all.cpu()
+        dist.all_gather_into_tensor(host_all, accum.cpu())
+        accum_all.copy_(host_all)
     return accum_all
