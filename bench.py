@@ -169,6 +169,11 @@ def main():
 
     for b in batches(seeds[: args.warmup]):
         render_passes(b)
+    # one more untimed launch of the timed launches' shape, so that the context's work buffers (fix-up
+    # records, hit list) have their final size before the clock starts
+    first = seeds[args.warmup: args.warmup + S]
+    if len(first) > args.warmup:
+        render_passes(first)
     tiles.gather_accum(accum, accum_all, world)  # untimed: RCCL sets its channels up on the first collective of a kind
     ctx.accum_resolve(m_accum_all, world, W, H, d_frame, d_env, pos, cdir)
     accum.zero_()
