@@ -129,3 +129,30 @@ def test_large_volume_64bit_indexing(gpu_ctx, orc):
     assert np.array_equal(g.contrib.pull(), o.contrib)
     assert np.array_equal(g.cache.pull(), o.cache)
     g.release()
+
+
+def test_4k_frame_pass_matches_the_oracle(full, orc):
+    """config 5's frame size (3840x2160) on one GPU: one voxel-cache pass and one image-space pass of the
+    same seed against the oracle; the two ranks of a 2-way tile split together give the same accumulation."""
+    w, h = 3840, 2160
+    vol, env, tf, pos, d = full["vol"], full["env"], full["tf"], full["pos"], full["d"]
+    ctx = full["g"].ctx
+    g = GpuScene(ctx, vol, full["sdf"], env, tf, (w, h), world=1)
+    threads = min(16, len(os.sched_getaffinity(0)))
+    o = orc.Scene(vol, full["sdf"], env, orc.parse_tf(tf), (w, h), threads=threads)
+    seed = scene.glibc_rand(1)[0]
+    g.render(pos, d, seed, debug=True, write_frame=False)
+    o.render(pos, d, seed)
+    assert np.array_equal(g.hit_index.pull(), o.hit_index)
+    assert np.array_equal(g.contrib.pull(), o.contrib)
+    assert np.array_equal(g.cache.pull(), o.cache)
+    g.release()
+    g = GpuScene(ctx, vol, full["sdf"], env, tf, (w, h), world=2)
+    merged = np.zeros((h, w, 4), np.float32)
+    for r in range(2):
+        g.render(pos, d, seed, mode=ffi.ACCUM_IMAGE_SPACE, rank=r, debug=False, write_frame=False)
+        merged += g.accum_row_major(r)
+    hit = o.hit_index.reshape(h, w) >= 0
+    assert np.array_equal(merged[hit][:, :3], o.contrib.reshape(h, w, 4)[hit][:, :3].astype(np.float32))
+    assert np.all(merged[hit][:, 3] == 1) and not merged[~hit].any()
+    g.release()
