@@ -6,6 +6,7 @@
 #include <memory>
 #include <string>
 
+#include "hdre_loader.hpp"
 #include "nrrd_loader.hpp"
 #include "renderer.hpp"
 
@@ -92,6 +93,14 @@ long long clvr_host_nrrd_probe(const char *path, unsigned dims[3], long long *ch
   for (short v : b.m_voxels) sum += v;
   *checksum = sum;
   return (long long)b.m_voxels.size();
+}
+// hdre_loader::load_file probe (no device involved): decodes into `out` (w*h*4 bytes) when it is large enough
+long long clvr_host_hdr_probe(const char *path, unsigned dims[2], unsigned char *out, long long out_bytes) {
+  hdre_loader loader;
+  image im = loader.load_file(path);
+  dims[0] = im.m_width; dims[1] = im.m_height;
+  if ((long long)im.m_pixels.size() <= out_bytes) std::memcpy(out, im.m_pixels.data(), im.m_pixels.size());
+  return (long long)im.m_pixels.size();
 }
 int clvr_host_sdf_layers(clvr_host *h) { return h->rend.distance_field().layers(); }
 void clvr_host_camera_direction(float alpha, float beta, float out[3]) {

@@ -197,3 +197,63 @@ def write_nrrd(path: str, vol: np.ndarray, use_gzip: bool = False) -> None:
     with open(path, "wb") as f:
         f.write(hdr.encode("ascii"))
         f.write(data)
+
+
+# ---------------------------------------------------------------------------------------------
+# Radiance RGBE (.hdr) writer + the LDR conversion the reference applies through stb_image
+# (app/hdre_loader.cpp:11-13: gamma 2.2, scale 1, 4 channels) -- used to test the C++ loader
+
+
+def float_to_rgbe(rgb: np.ndarray) -> np.ndarray:
+    """[h][w][3] float32 -> [h][w][4] uint8 (shared exponent)"""
+    m = rgb.max(axis=-1)
+    out = np.zeros(rgb.shape[:-1] + (4,), dtype=np.uint8)
+    nz = m > 1e-32
+    mant, exp = np.frexp(m[nz])
+    scale = (mant * 256.0 / m[nz])[:, None]
+    out[nz, :3] = np.clip(rgb[nz] * scale, 0, 255).astype(np.uint8)
+    out[nz, 3] = (exp + 128).astype(np.uint8)
+    return out
+
+
+def write_hdr(path: str, rgbe: np.ndarray, rle: bool = True) -> None:
+    h, w, _ = rgbe.shape
+    with open(path, "wb") as f:
+        f.write(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w))
+        if not rle or w < 8 or w >= 32768:
+            f.write(rgbe.tobytes())
+            return
+        for j in range(h):
+            f.write(bytes([2, 2, w >> 8, w & 255]))
+            for k in range(4):
+                ch = rgbe[j, :, k]
+                i = 0
+                while i < w:
+                    run = 1
+                    while i + run < w and run < 127 and ch[i + run] == ch[i]:
+                        run += 1
+                    if run >= 3:
+                        f.write(bytes([128 + run, int(ch[i])]))
+                        i += run
+                    else:
+                        lit = 1
+                        while i + lit < w and lit < 128 and not (
+                                i + lit + 2 < w and ch[i + lit] == ch[i + lit + 1] == ch[i + lit + 2]):
+                            lit += 1
+                        f.write(bytes([lit]) + ch[i:i + lit].tobytes())
+                        i += lit
+
+
+def rgbe_to_ldr(rgbe: np.ndarray) -> np.ndarray:
+    """what hdre_loader must produce: [h][w][4] uint8"""
+    e = rgbe[..., 3].astype(np.int32)
+    f = np.ldexp(np.float32(1.0), e - 136).astype(np.float32)
+    lin = rgbe[..., :3].astype(np.float32) * f[..., None]
+    lin[e == 0] = 0
+    inv_gamma = np.float32(1) / np.float32(2.2)
+    z = np.power(lin.astype(np.float64), np.float64(inv_gamma)).astype(np.float32) * np.float32(255) + np.float32(0.5)
+    z = np.clip(z, 0, 255)
+    out = np.empty(rgbe.shape, dtype=np.uint8)
+    out[..., :3] = z.astype(np.int32).astype(np.uint8)
+    out[..., 3] = 255
+    return out

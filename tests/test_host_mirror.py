@@ -196,3 +196,25 @@ def test_reference_sdf_test_program():
                           os.path.join(ROOT, "tests", "golden", "sdf_values.x")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "EVERYTHING FINE" in out.stdout and "13 layers" in out.stdout
+
+
+@pytest.mark.parametrize("rle,w", [(True, 64), (False, 64), (True, 5), (True, 300)])
+def test_hdre_loader_decodes_radiance_files(tmp_path, rle, w):
+    """app/hdre_loader.cpp mirror (CPU only): RGBE decode + gamma-2.2 LDR conversion; parity unpinned (the
+    reference ships no .hdr file), checked against the numpy statement of the same formula."""
+    L = _host()
+    L.clvr_host_hdr_probe.restype = C.c_longlong
+    L.clvr_host_hdr_probe.argtypes = [C.c_char_p, C.POINTER(C.c_uint), C.c_void_p, C.c_longlong]
+    rng = np.random.default_rng(w)
+    h = 17
+    rgb = (rng.random((h, w, 3), dtype=np.float32) ** 3 * 4.0).astype(np.float32)
+    rgb[:, : w // 3] = rgb[:, :1]      # long runs for the RLE path
+    rgb[0, 0] = 0.0
+    rgbe = scene.float_to_rgbe(rgb)
+    path = str(tmp_path / "env.hdr")
+    scene.write_hdr(path, rgbe, rle=rle)
+    dims = (C.c_uint * 2)()
+    out = np.zeros((h, w, 4), np.uint8)
+    n = L.clvr_host_hdr_probe(path.encode(), dims, out.ctypes.data, out.nbytes)
+    assert n == out.nbytes and list(dims) == [w, h]
+    assert np.array_equal(out, scene.rgbe_to_ldr(rgbe))
