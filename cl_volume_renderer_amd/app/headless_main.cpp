@@ -1,0 +1,73 @@
+// headless_main.cpp -- the reference application's start-up and frame loop without the window:
+// main (app/main.cpp:8-18) + the parts of ui::run that drive the frame_emitter (app/ui.cpp:170-199, 296).
+// Usage: clvr_headless <volume.nrrd> <env.hdr> [frames=16] [width=1920] [height=1080] [out.ppm]
+// Prints one JSON line with the frame time and a checksum of the last frame.
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+
+#include "common_defines.hpp"
+#include "hdre_loader.hpp"
+#include "nrrd_loader.hpp"
+#include "renderer.hpp"
+#include "tf_part.hpp"
+
+int main(int argc, char const *argv[]) {
+  if (argc < 3) {
+    std::cout << "Usage: " << argv[0] << " <path to nrrd file> <path to envmap> [frames] [width] [height] [out.ppm]\n";
+    return 1;
+  }
+  const int frames = argc > 3 ? std::atoi(argv[3]) : 16;
+  const int width = argc > 4 ? std::atoi(argv[4]) : 1920;
+  const int height = argc > 5 ? std::atoi(argv[5]) : 1080;
+
+  clw_context ctx;
+  renderer r(ctx);
+  frame_emitter *emitter = &r;
+
+  nrrd_loader vloader;
+  volume_block v = vloader.load_file(argv[1]);
+  reference_volume rv(ctx, &v);
+  rv.set_value_clip({-2000, 3000});
+  rv.set_gradient_clip({0, 4000});
+  hdre_loader iloader;
+  image em = iloader.load_file(argv[2]);
+  env_map emap(ctx, em);
+  emitter->image_set(&rv, &emap);
+
+  std::vector<tf_selection *> selection{new tf_rect_selection(0, 500.f, 1200.f, 0.0f, 4000.f)};
+  emitter->next_event_code_set(tf_generate_source(rv.get_volume_stats(), selection));
+  emitter->flush_changes();
+
+  ui_state state{argv[1], true, height, width, Position3D(-200, 200, -200), {0.9f, 6.183f}, true};
+  const double scale = rv.get_volume_size()[0] / 512.0;  // the default camera is placed for a 512^3 volume
+  state.position = Position3D(-200 * scale, 200 * scale, -200 * scale);
+  const unsigned char *frame = nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int f = 0; f < frames; ++f) {
+    bool changed = false;
+    state.cam_changed = true;  // progressive refinement: keep sampling the same view
+    frame = static_cast<const unsigned char *>(emitter->render_frame(state, changed));
+  }
+  const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+  std::uint64_t checksum = 1469598103934665603ull;  // FNV-1a over the launched region of the frame
+  for (int y = 0; y < height; ++y)
+    for (int x = 0; x < width * 4; ++x) {
+      checksum ^= frame[(size_t)y * SCREEN_WIDTH * 4 + x];
+      checksum *= 1099511628211ull;
+    }
+  if (argc > 6) {
+    std::ofstream ppm(argv[6], std::ios::binary);
+    ppm << "P6\n" << width << " " << height << "\n255\n";
+    for (int y = height - 1; y >= 0; --y)  // row 0 is the bottom of the screen
+      for (int x = 0; x < width; ++x) ppm.write(reinterpret_cast<const char *>(frame + ((size_t)y * SCREEN_WIDTH + x) * 4), 3);
+  }
+  std::printf("{\"frames\": %d, \"width\": %d, \"height\": %d, \"seconds\": %.6f, \"ms_per_frame\": %.4f, \"frame_fnv1a\": \"%016llx\"}\n",
+              frames, width, height, seconds, seconds * 1e3 / frames, (unsigned long long)checksum);
+  for (tf_selection *s : selection) delete s;
+  return 0;
+}

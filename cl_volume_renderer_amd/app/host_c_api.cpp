@@ -9,6 +9,7 @@
 #include "hdre_loader.hpp"
 #include "nrrd_loader.hpp"
 #include "renderer.hpp"
+#include "tf_part.hpp"
 
 struct clvr_host {
   clw_context ctx;
@@ -101,6 +102,21 @@ long long clvr_host_hdr_probe(const char *path, unsigned dims[2], unsigned char 
   dims[0] = im.m_width; dims[1] = im.m_height;
   if ((long long)im.m_pixels.size() <= out_bytes) std::memcpy(out, im.m_pixels.data(), im.m_pixels.size());
   return (long long)im.m_pixels.size();
+}
+// ui::flush_tf string for a list of rectangles {min_v, max_v, min_g, max_g, r, g, b, a} (no device involved)
+long long clvr_host_tf_source(const float *rects, int n, const float stats[4], char *out, long long out_bytes) {
+  std::vector<tf_selection *> sel;
+  for (int i = 0; i < n; ++i) {
+    auto *r = new tf_rect_selection((unsigned)i, rects[i * 8 + 0], rects[i * 8 + 1], rects[i * 8 + 2], rects[i * 8 + 3]);
+    for (int c = 0; c < 4; ++c) r->color[c] = rects[i * 8 + 4 + c];
+    sel.push_back(r);
+  }
+  Volume_Stats st;
+  st.min_v = stats[0]; st.max_v = stats[1]; st.min_g = stats[2]; st.max_g = stats[3];
+  const std::string code = tf_generate_source(st, sel);
+  for (auto *s : sel) delete s;
+  if ((long long)code.size() + 1 <= out_bytes) std::memcpy(out, code.c_str(), code.size() + 1);
+  return (long long)code.size();
 }
 int clvr_host_sdf_layers(clvr_host *h) { return h->rend.distance_field().layers(); }
 void clvr_host_camera_direction(float alpha, float beta, float out[3]) {

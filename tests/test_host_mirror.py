@@ -218,3 +218,64 @@ def test_hdre_loader_decodes_radiance_files(tmp_path, rle, w):
     n = L.clvr_host_hdr_probe(path.encode(), dims, out.ctypes.data, out.nbytes)
     assert n == out.nbytes and list(dims) == [w, h]
     assert np.array_equal(out, scene.rgbe_to_ldr(rgbe))
+
+
+def test_tf_source_generator_matches_the_reference_format():
+    """tf_rect_selection::create_cl_condition + ui::flush_tf (app/tf_part.cpp:55-79, app/ui.cpp:160-168):
+    the C++ generator and the Python statement of the same format produce the same text, and the product's
+    parser accepts it."""
+    from cl_volume_renderer_amd import ffi
+
+    L = _host()
+    L.clvr_host_tf_source.restype = C.c_longlong
+    L.clvr_host_tf_source.argtypes = [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.c_char_p, C.c_longlong]
+    rects = [(500.0, 1200.0, 0.0, 4000.0, (1.0, 1.0, 1.0, 1.0)),
+             (812.5, 900.25, 100.0, 4000.0, (0.5, 0.25, 1.0, 0.0)),
+             (-100.0, 1e-3, 10.5, 20.5, (0.1, 0.2, 0.3, 0.4))]
+    stats = (-2000.0, 3000.0, 0.0, 4000.0)
+    flat = []
+    for r in rects:
+        flat += [r[0], r[1], r[2], r[3], *r[4]]
+    buf = C.create_string_buffer(4096)
+    n = L.clvr_host_tf_source((C.c_float * len(flat))(*flat), len(rects), (C.c_float * 4)(*stats), buf, 4096)
+    code = buf.value.decode()
+    assert n == len(code)
+    assert code == scene.tf_rect_source(rects, stats)
+    assert code.startswith("inline bool is_event_gen(short value, short gradient, int4 *color){\n  if(value >= 500 && value <= 1200)\n {")
+    assert ffi.parse_tf(code).n == 3
+
+
+@pytest.mark.gpu
+def test_headless_application_renders_the_oracles_frame(orc, tmp_path):
+    """main.cpp + the frame_emitter part of ui::run without the window: NRRD + .hdr from disk, default TF,
+    N frames with std::rand() seeds; the frame's checksum equals the oracle's resolved frame."""
+    import json
+    import subprocess
+
+    n = 48
+    vol = scene.phantom(n)
+    scene.write_nrrd(str(tmp_path / "v.nrrd"), vol, use_gzip=True)
+    rng = np.random.default_rng(5)
+    rgbe = scene.float_to_rgbe((rng.random((64, 128, 3), dtype=np.float32) * 1.5).astype(np.float32))
+    scene.write_hdr(str(tmp_path / "e.hdr"), rgbe)
+    env = scene.rgbe_to_ldr(rgbe)
+    W, H, frames = 160, 96, 3
+    exe = os.path.join(ROOT, "cl_volume_renderer_amd", "clvr_headless")
+    out = subprocess.run([exe, str(tmp_path / "v.nrrd"), str(tmp_path / "e.hdr"), str(frames), str(W), str(H)],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+
+    tf = scene.tf_default_source()
+    sdf, _, _ = orc.sdf_build(vol, orc.parse_tf(tf))
+    o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (2048, 1024), (W, H))
+    s = n / 512.0
+    pos = np.array([-200 * s, 200 * s, -200 * s], np.float32)
+    d = scene.camera_direction(0.9, 6.183)
+    for seed in scene.glibc_rand(frames):
+        o.render(pos, d, seed)
+    o.resolve(pos, d)
+    h = 1469598103934665603
+    for b in o.frame[:H, :W].tobytes():
+        h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    assert got["frame_fnv1a"] == "%016x" % h
