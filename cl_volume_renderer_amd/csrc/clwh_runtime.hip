@@ -5,6 +5,7 @@
 // a registry of precompiled gfx950 kernels keyed by the reference's (file, entry) names, and the
 // transfer-function source parsed into a launch-time table instead of being JIT-compiled.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -16,6 +17,11 @@
 using namespace clvr;
 
 static thread_local int g_last_hip_error = 0;
+
+// Content versions are drawn from one process-wide counter, so (device pointer, version) identifies a
+// content uniquely even when an object is released and another one is allocated at the same address.
+static std::atomic<uint64_t> g_content_version{0};
+static inline void touch(clwh_mem *m) { m->version = ++g_content_version; }
 
 #define HIP_TRY(expr)                                   \
   do {                                                  \
@@ -182,6 +188,7 @@ static int mem_new(clwh_ctx *ctx, void *dptr, size_t bytes, bool owned, clwh_mem
   m->dptr = dptr;
   m->bytes = bytes;
   m->owned = owned;
+  touch(m);
   *out = m;
   return CLWH_OK;
 }
@@ -255,7 +262,7 @@ int clwh_mem_push(clwh_ctx *ctx, clwh_mem *mem, const void *host, size_t bytes) 
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipMemcpyAsync(mem->dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  mem->version++;
+  touch(mem);
   return CLWH_OK;
 }
 
@@ -288,7 +295,7 @@ void *clwh_mem_device_ptr(clwh_mem *mem) { return mem ? mem->dptr : nullptr; }
 size_t clwh_mem_size(clwh_mem *mem) { return mem ? mem->bytes : 0; }
 int clwh_mem_mark_dirty(clwh_mem *mem) {
   if (!mem) return CLWH_ERR_INVALID_VALUE;
-  mem->version++;
+  touch(mem);
   return CLWH_OK;
 }
 
@@ -565,7 +572,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   ctx->fixup_overflow_pending = true;
   if (ctx->timing) HIP_TRY(hipEventRecord(ev_e, ctx->stream));
   if (d->write_frame && a.frame) HIP_TRY(launch_resolve(a, ctx->stream));
-  if (d->frame) d->frame->version++;
+  if (d->frame) touch(d->frame);
   return CLWH_OK;
 }
 
@@ -586,7 +593,7 @@ int clwh_accum_resolve(clwh_ctx *ctx, clwh_mem *accum_all, int32_t tile_world, u
   a.env_h = (int32_t)env->dims[1];
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(launch_accum_resolve(a, (const float4 *)accum_all->dptr, ctx->stream));
-  frame->version++;
+  touch(frame);
   return CLWH_OK;
 }
 
@@ -601,7 +608,7 @@ int clwh_buffer_reset(clwh_ctx *ctx, clwh_mem *buffer_volume) {
   if (!ctx || !buffer_volume) return CLWH_ERR_INVALID_VALUE;
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipMemsetAsync(buffer_volume->dptr, 0, buffer_volume->bytes, ctx->stream));
-  buffer_volume->version++;
+  touch(buffer_volume);
   return CLWH_OK;
 }
 
@@ -694,7 +701,7 @@ int clwh_sdf_build(clwh_ctx *ctx, clwh_mem *volume, const char *tf_source, clwh_
     }
     *n_launches = launches;
   }
-  sdf->version++;
+  touch(sdf);
   return CLWH_OK;
 }
 
@@ -773,7 +780,7 @@ int clwh_launch(clwh_kernel *k, const size_t global_in[3], const size_t local_in
       if (v->dims[1] > 65535 || v->dims[2] > 65535) return CLWH_ERR_INVALID_VALUE;
       HIP_TRY(launch_fetch_stats((const int16_t *)v->dptr, (int)v->dims[0], (int)v->dims[1], (int)v->dims[2],
                                  (int32_t *)st->dptr, ctx->stream));
-      st->version++;
+      touch(st);
       return CLWH_OK;
     }
 
@@ -790,7 +797,7 @@ int clwh_launch(clwh_kernel *k, const size_t global_in[3], const size_t local_in
       if (v->dims[1] > 65535 || v->dims[2] > 65535) return CLWH_ERR_INVALID_VALUE;
       HIP_TRY(launch_tf_sort_values((const int16_t *)v->dptr, (int)v->dims[0], (int)v->dims[1], (int)v->dims[2],
                                     (uint32_t *)fr->dptr, w, h, f[0], f[1], f[2], f[3], ctx->stream));
-      fr->version++;
+      touch(fr);
       return CLWH_OK;
     }
 
@@ -804,7 +811,7 @@ int clwh_launch(clwh_kernel *k, const size_t global_in[3], const size_t local_in
       if (fr->bytes < fw * fh * 4u || len < 0 || lk->bytes < (size_t)len * 4u) return CLWH_ERR_SIZE_MISMATCH;
       HIP_TRY(launch_tf_flush_color_frame((uint32_t *)cf->dptr, (int)fw, (int)fh, (const int32_t *)fr->dptr,
                                           (const int32_t *)lk->dptr, len, ctx->stream));
-      cf->version++;
+      touch(cf);
       return CLWH_OK;
     }
 
@@ -818,7 +825,7 @@ int clwh_launch(clwh_kernel *k, const size_t global_in[3], const size_t local_in
       HIP_TRY(launch_apply_clip((const int16_t *)src->dptr, (int)src->dims[0], (int)src->dims[1], (int)src->dims[2],
                                 (int16_t *)dst->dptr, (int)dst->dims[0], (int)dst->dims[1], (int)dst->dims[2],
                                 (const uint32_t *)start->dptr, (const uint32_t *)len->dptr, ctx->stream));
-      dst->version++;
+      touch(dst);
       return CLWH_OK;
     }
 
@@ -842,8 +849,8 @@ int clwh_launch(clwh_kernel *k, const size_t global_in[3], const size_t local_in
       a.max_iterations = max_it;
       tf_to_dev(k->tf, a.tf);
       HIP_TRY(launch_sdf_base(a, ctx->stream));
-      ping->version++;
-      pong->version++;
+      touch(ping);
+      touch(pong);
       return CLWH_OK;
     }
 
@@ -867,8 +874,8 @@ int clwh_launch(clwh_kernel *k, const size_t global_in[3], const size_t local_in
       a.max_iterations = max_it;
       a.counter_out = (int32_t *)counter->dptr;
       HIP_TRY(launch_sdf_layer(a, ctx->stream));
-      outm->version++;
-      counter->version++;
+      touch(outm);
+      touch(counter);
       return CLWH_OK;
     }
   }

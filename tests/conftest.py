@@ -12,6 +12,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """Build the product libraries when they are missing (hipcc cross-compiles for gfx950 without a GPU);
+    on the GPU box the prebuilt files travel with the snapshot and nothing happens here."""
+    from cl_volume_renderer_amd import build as product_build
+
+    try:
+        if not os.path.exists(product_build.LIB):
+            product_build.build()
+        if not os.path.exists(product_build.HOST_LIB):
+            product_build.build_host()
+    except Exception as e:  # the tests that need the libraries will fail loudly with the real reason
+        print("warning: could not build the product libraries:", e, file=sys.stderr)
+
+
 @pytest.fixture(scope="session")
 def orc():
     """The CPU oracle (test infrastructure).  Built on demand with gcc."""

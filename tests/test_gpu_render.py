@@ -277,3 +277,37 @@ def test_gradient_tf_literal_taps_agree_with_baked_class(orc):
         g.release()
         ctx.destroy()
     os.environ.pop("CLWH_TUNE_LITERAL_GRADIENT", None)
+
+
+def test_released_and_reallocated_images_do_not_alias_derived_data(orc):
+    """a new volume allocated where a released one lived (same size -> usually the same device address)
+    must not be mistaken for the old content by the packed-record / primary-hit caches."""
+    ctx = ffi.Context(0)
+    tf = scene.tf_default_source()
+    env = scene.env_map(128, 64)
+    d_env = ctx.image_from(env, channels=4)
+    w, h = 96, 96
+    frame = ctx.image([w, h], 4, np.uint8, (h, w, 4))
+    k = ctx.kernel("ray_marching.cl", "render", tf)
+    addresses = []
+    for variant in range(2):
+        vol = scene.phantom(40, seed=1234 + variant)
+        if variant:
+            vol = np.ascontiguousarray(vol[:, ::-1])
+        sdf, _, _ = orc.sdf_build(vol, orc.parse_tf(tf))
+        d_vol, d_sdf = ctx.image_from(vol), ctx.image_from(sdf)
+        addresses.append((d_vol.device_ptr, d_sdf.device_ptr))
+        cache = ctx.buffer(ffi.cache_len(40, 40, 40) * 2, np.uint16)
+        ctx.buffer_reset(cache)
+        pos, d = look_at_centre(vol, [-18, 35, -16])
+        o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (w, h))
+        for s in (11, 12):
+            k.render(frame=frame, volume=d_vol, sdf=d_sdf, env=d_env, buffer_volume=cache, cam_pos=pos, cam_dir=d,
+                     seed=s, width=w, height=h)
+            o.render(pos, d, s)
+        assert np.array_equal(cache.pull(), o.cache), "variant %d" % variant
+        for m in (d_vol, d_sdf, cache):
+            m.release()
+    # informational: on this allocator the second pair normally reuses the first pair's addresses
+    print("device addresses", addresses)
+    ctx.destroy()
