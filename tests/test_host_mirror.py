@@ -279,3 +279,21 @@ def test_headless_application_renders_the_oracles_frame(orc, tmp_path):
     for b in o.frame[:H, :W].tobytes():
         h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
     assert got["frame_fnv1a"] == "%016x" % h
+
+
+def test_fail_hard_error_convention_without_a_device():
+    """clw_fail_hard_on_error (reference opencl_wrapper/include/clw_helper.hpp:293-309): any failing call
+    prints the call site and the error name to stderr and exits with status 1.  Without a GPU the very
+    first call -- clw_context's constructor -- fails, which is exactly the convention to observe."""
+    import subprocess
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    exe = os.path.join(ROOT, "cl_volume_renderer_amd", "sdf_test")
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "sdf_testdata.nrrd"),
+                          os.path.join(ROOT, "tests", "golden", "sdf_values.x")], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1
+    assert "CLWH_ERR_NO_DEVICE" in out.stderr and "Exiting application" in out.stderr
+    assert "File      :" in out.stderr and "Line      :" in out.stderr
