@@ -218,7 +218,11 @@ __global__ __launch_bounds__(256) void k_sdf_front(const SdfFrontArgs a) {
         const int8_t *row = a.sdf + ((size_t)gz * (size_t)a.Y + (size_t)gy) * (size_t)a.X;
         int8_t *dst = &s_region[wave][rz * kSliceStride + ry * kRowStride];
         if (wide) {
-          *reinterpret_cast<uint4 *>(dst) = *reinterpret_cast<const uint4 *>(row + x0 - 4);
+          // 16 bytes [x0-4, x0+12): the source is only 4-byte aligned (x0 - 4 = 4 mod 8), so four dword loads
+          const uint32_t *src = reinterpret_cast<const uint32_t *>(row + x0 - 4);
+          uint4 v;
+          v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
+          *reinterpret_cast<uint4 *>(dst) = v;
         } else {
 #pragma unroll
           for (int rx = 0; rx < 10; ++rx) dst[3 + rx] = row[min(max(x0 - 1 + rx, 0), a.X - 1)];
