@@ -57,6 +57,16 @@ def image_space_bytes(c, samples):
     return (c["n_sdf"] + 2 * c["n_vol"] + 4 * c["n_env"] + 32 * c["n_add"] + 8 * samples) / float(samples)
 
 
+def measured_traffic(world, N, W, H, launches, args):
+    """HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
+    (bench.py cannot run the profiler on itself); only reported for the launch shape that was profiled."""
+    path = os.path.join(ROOT, "profiles", "r01_k_bounce_traffic.json")
+    if world != 1 or (N, W, H, args.steps, launches, args.tf) != (512, 1920, 1080, 64, 1, "default") or not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    return round((t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]) / 1e9, 3)
+
+
 def voxel_cache_bytes(c, samples):
     """B = N_sdf + 2 N_vol + 4 N_env + 4 N_tok + 8 N_add + 8 N_read + 4."""
     return (c["n_sdf"] + 2 * c["n_vol"] + 4 * c["n_env"] + 4 * c["n_tok"] + 8 * c["n_add"]
@@ -259,8 +269,9 @@ def main():
             "achieved": round(achieved, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
+            "traffic_unit": "GB per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, raw)",
             "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": None,
+            "traffic": measured_traffic(world, N, W, H, kern_n, args),
             "bytes_per_sample": round(bps, 3),
             "samples_per_launch": int(own_px * spl),
             "avg_launch_ms": round(avg_ms, 4),

@@ -61,6 +61,7 @@ struct RenderArgs {
   float cam_dir[3];
   int32_t mode;            // clwh_accum_mode
   float4 *accum;           // tile-major float4 per pixel slot (mode 1)
+  unsigned long long *delta;  // mode 1: this launch's packed sums per hit (see finish_item / k_commit)
   uint32_t *pix_slot;      // tile-major, per pixel: PIX_HIT | hit index, or the miss colour
   HitRec *hits;            // compacted primary hits of this camera
   uint32_t *counters;      // [0] hits (k_primary), [2] fix-up records, [3] fix-up overflow flag, [32*(q+1)] unit-queue heads, one per 128-B line
@@ -111,6 +112,7 @@ hipError_t launch_repack(const RepackArgs &a, hipStream_t s);
 hipError_t launch_primary(const RenderArgs &a, hipStream_t s);
 hipError_t launch_bounce(const RenderArgs &a, hipStream_t s);
 hipError_t launch_env_fixup(const RenderArgs &a, hipStream_t s);
+hipError_t launch_commit(const RenderArgs &a, hipStream_t s);
 hipError_t launch_resolve(const RenderArgs &a, hipStream_t s);
 hipError_t launch_accum_resolve(const RenderArgs &a, const float4 *accum_all, hipStream_t s);
 // ---- fused SDF build: one breadth-first layer over the active 8x8x8 tiles (sdf_kernels.hip)
@@ -154,6 +156,8 @@ struct clwh_ctx {
   static constexpr size_t kRenderCounters = 32 * 9;
   uint32_t *fixups = nullptr;
   size_t fixups_bytes = 0;
+  unsigned long long *delta = nullptr;
+  size_t delta_bytes = 0;
   bool fixup_overflow_pending = false;
   // measured on MI355X (profiles/r01_tune_*.txt): a wave that runs its 64 samples to completion with
   // steps and events in separate wave-wide phases beats mid-flight refills (12.5 vs 7.6 Gsamples/s)

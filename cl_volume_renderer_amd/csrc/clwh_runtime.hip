@@ -111,6 +111,7 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
   if (ctx->hits) (void)hipFree(ctx->hits);
   if (ctx->render_counters) (void)hipFree(ctx->render_counters);
   if (ctx->fixups) (void)hipFree(ctx->fixups);
+  if (ctx->delta) (void)hipFree(ctx->delta);
   if (ctx->sdf_counters) (void)hipFree(ctx->sdf_counters);
   if (ctx->sdf_flags) (void)hipFree(ctx->sdf_flags);
   if (ctx->packed) (void)hipFree(ctx->packed);
@@ -559,6 +560,12 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   if (rc != CLWH_OK) return rc;
   a.fixups = ctx->fixups;
   a.fixup_capacity = (uint32_t)std::min<size_t>(ctx->fixups_bytes / 128u, 0x7fffffffu);
+  if (a.mode == CLWH_ACCUM_IMAGE_SPACE) {
+    rc = grow(ctx, (void **)&ctx->delta, &ctx->delta_bytes, std::max<size_t>(a.n_hits, 1) * sizeof(unsigned long long));
+    if (rc != CLWH_OK) return rc;
+    a.delta = ctx->delta;
+    HIP_TRY(hipMemsetAsync(ctx->delta, 0, (size_t)a.n_hits * sizeof(unsigned long long), ctx->stream));
+  }
   HIP_TRY(hipMemsetAsync(ctx->render_counters + 1, 0, (clwh_ctx::kRenderCounters - 1) * sizeof(uint32_t), ctx->stream));
   if (a.contrib_out) HIP_TRY(hipMemsetAsync(a.contrib_out, 0, npx * 16, ctx->stream));  // misses contribute nothing
   hipEvent_t ev_b = nullptr, ev_e = nullptr;
@@ -569,6 +576,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   }
   HIP_TRY(launch_bounce(a, ctx->stream));
   HIP_TRY(launch_env_fixup(a, ctx->stream));
+  HIP_TRY(launch_commit(a, ctx->stream));
   ctx->fixup_overflow_pending = true;
   if (ctx->timing) HIP_TRY(hipEventRecord(ev_e, ctx->stream));
   if (d->write_frame && a.frame) HIP_TRY(launch_resolve(a, ctx->stream));

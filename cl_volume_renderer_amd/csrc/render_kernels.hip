@@ -179,25 +179,42 @@ __global__ __launch_bounds__(64) void k_primary(const RenderArgs a) {
 enum : int { ST_IDLE = 0, ST_MARCH = 1, ST_EVENT = 2 };
 enum : int { EV_START = 3 };            // a freshly fetched item: start distribution ray 1
 
+// Image-space accumulation of one launch: a sample adds r | g<<16 | b<<32 | 1<<48 to its HIT's 64-bit
+// delta with ONE atomic (a launch has at most 64 seeds and a contribution is at most 255, so no field can
+// carry); k_commit then folds the deltas into the caller's float4 buffer with plain read-modify-writes.
+// Four float atomics per sample were a quarter of the kernel's L2-missing requests.
 template <int MODE>
-__device__ __forceinline__ void finish_item(const RenderArgs &a, int64_t entry, uint32_t pslot, uint32_t gx,
-                                            uint32_t gy, uint32_t bv_r, uint32_t bv_g, uint32_t bv_b) {
+__device__ __forceinline__ void finish_item(const RenderArgs &a, int64_t entry, uint32_t hit, uint32_t gx, uint32_t gy,
+                                            uint32_t bv_r, uint32_t bv_g, uint32_t bv_b) {
   // ray_marching.cl:75-76: halve (dist_count = 2), then add
   const uint32_t cr = (bv_r / 2u) & 0xFFFFu, cg = (bv_g / 2u) & 0xFFFFu, cb = (bv_b / 2u) & 0xFFFFu;
   if (MODE == CLWH_ACCUM_VOXEL_CACHE) {
     cache_add(a.cache, entry, cr, cg, cb, 0u);
   } else {
-    float *acc = reinterpret_cast<float *>(a.accum + pslot);
-    // integer-valued floats: every partial sum is exact, so the order of the atomics does not matter
-    atomicAdd(acc + 0, (float)cr);
-    atomicAdd(acc + 1, (float)cg);
-    atomicAdd(acc + 2, (float)cb);
-    atomicAdd(acc + 3, 1.0f);
+    const unsigned long long packed = (unsigned long long)cr | ((unsigned long long)cg << 16) |
+                                      ((unsigned long long)cb << 32) | (1ull << 48);
+    atomicAdd(a.delta + hit, packed);
   }
   if (a.contrib_out) {
     uint32_t *q = a.contrib_out + ((size_t)gy * (size_t)a.launch_w + gx) * 4;
     q[0] = cr; q[1] = cg; q[2] = cb; q[3] = 1u;
   }
+}
+
+// fold one launch's per-hit deltas into the float4 accumulation buffer (one lane per hit = per pixel)
+__global__ __launch_bounds__(256) void k_commit(const RenderArgs a) {
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= a.n_hits) return;
+  const unsigned long long d = a.delta[h];
+  if (d == 0ull) return;
+  const uint32_t pslot = a.hits[h].pslot;
+  float4 acc = a.accum[pslot];
+  // integer-valued floats below 2^24: exact
+  acc.x += (float)(uint32_t)(d & 0xFFFFull);
+  acc.y += (float)(uint32_t)((d >> 16) & 0xFFFFull);
+  acc.z += (float)(uint32_t)((d >> 32) & 0xFFFFull);
+  acc.w += (float)(uint32_t)(d >> 48);
+  a.accum[pslot] = acc;
 }
 
 // Environment lookups use the certified fast path (env_fast.hpp).  A lookup that cannot be certified
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
   int npend = 0;   // pending environment terms written to it
 
   // the sample
-  uint32_t gx = 0, gy = 0, pslot = 0;
+  uint32_t gx = 0, gy = 0, hit = 0;  // global pixel, hit index
   int seed = 0;
   int64_t entry = -1;
   f3 hit_origin{0, 0, 0}, hit_direction{0, 0, 0}, normal{0, 0, 0};  // hit_information + its normal
@@ -286,7 +303,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
           entry = (int64_t)(((uint64_t)q2.w << 32) | (uint64_t)q2.z);
           gx = q3.x & 0xFFFFu;
           gy = q3.x >> 16;
-          pslot = q3.y;
+          hit = h;
           seed = a.seeds[s];
           bool granted = true;
           if (MODE == CLWH_ACCUM_VOXEL_CACHE) granted = entry >= 0 && cache_take_token(a.cache, entry, 256u);
@@ -363,7 +380,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
             if (slot < a.fixup_capacity) {
               fix = (int)slot;
               uint32_t *rec = a.fixups + (size_t)slot * kFixupDwords;
-              rec[0] = pslot;
+              rec[0] = hit;
               rec[1] = (uint32_t)((uint64_t)entry & 0xFFFFFFFFull);
               rec[2] = (uint32_t)((uint64_t)entry >> 32);
               rec[3] = gx | (gy << 16);
@@ -413,7 +430,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
 
       if (start_path) {
         if (o > 2) {
-          if (fix == -1) finish_item<MODE>(a, entry, pslot, gx, gy, bv_r, bv_g, bv_b);
+          if (fix == -1) finish_item<MODE>(a, entry, hit, gx, gy, bv_r, bv_g, bv_b);
           else if (fix >= 0) a.fixups[(size_t)fix * kFixupDwords + 7] = (uint32_t)npend;  // k_env_fixup finishes it
           st = ST_IDLE;
         } else {
@@ -464,7 +481,7 @@ __global__ __launch_bounds__(256) void k_env_fixup(const RenderArgs a) {
   if (n > a.fixup_capacity) n = a.fixup_capacity;
   for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
     const uint32_t *rec = a.fixups + (size_t)k * kFixupDwords;
-    const uint32_t pslot = rec[0];
+    const uint32_t hit = rec[0];
     const int64_t entry = (int64_t)(((uint64_t)rec[2] << 32) | (uint64_t)rec[1]);
     const uint32_t gx = rec[3] & 0xFFFFu, gy = rec[3] >> 16;
     uint32_t bv_r = rec[4], bv_g = rec[5], bv_b = rec[6];
@@ -479,7 +496,7 @@ __global__ __launch_bounds__(256) void k_env_fixup(const RenderArgs a) {
       bv_g = f2u((float)bv_g + p_g * (float)((light >> 8) & 255u) * factor / 1.0f);
       bv_b = f2u((float)bv_b + p_b * (float)((light >> 16) & 255u) * factor / 1.0f);
     }
-    finish_item<MODE>(a, entry, pslot, gx, gy, bv_r, bv_g, bv_b);
+    finish_item<MODE>(a, entry, hit, gx, gy, bv_r, bv_g, bv_b);
   }
 }
 
@@ -577,6 +594,12 @@ hipError_t launch_env_fixup(const RenderArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(k_env_fixup<CLWH_ACCUM_VOXEL_CACHE>, dim3(64), dim3(256), 0, s, a);
   else
     hipLaunchKernelGGL(k_env_fixup<CLWH_ACCUM_IMAGE_SPACE>, dim3(64), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_commit(const RenderArgs &a, hipStream_t s) {
+  if (a.n_hits == 0 || a.mode != CLWH_ACCUM_IMAGE_SPACE) return hipSuccess;
+  hipLaunchKernelGGL(k_commit, dim3((a.n_hits + 255u) / 256u), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

@@ -12,5 +12,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH -
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --steps 64 --warmup 0 > /dev/null 2> "$OUT/pmc_fetch.err" || { tail -5 "$OUT/pmc_fetch.err"; exit 1; }
 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$OUT/pmc_write" -- $BENCH --steps 64 --warmup 0 > /dev/null 2> "$OUT/pmc_write.err" || { tail -5 "$OUT/pmc_write.err"; exit 1; }
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d "$OUT/pmc_sq" -- $BENCH --steps 64 --warmup 0 > /dev/null 2> "$OUT/pmc_sq.err" || { tail -5 "$OUT/pmc_sq.err"; exit 1; }
-python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.txt"
+python3 tools/summarize_prof.py "$OUT" "$OUT/k_bounce_traffic.json" > "$OUT/summary.txt"
 cat "$OUT/summary.txt"

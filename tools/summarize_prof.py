@@ -45,5 +45,25 @@ def main(d):
                 print("%-50s %-24s n=%-4d %16.1f%s" % (k[:50], c, len(v), m, extra))
 
 
+def traffic_json(d, out_path):
+    """HBM-side traffic of the dominant kernel per launch, from the separate FETCH_SIZE and WRITE_SIZE passes
+    (KiB -> bytes; raw, see MI355X_MICROARCH.md: the x2 correction applies to wide streams, not to 64-B gathers)."""
+    import json
+
+    vals = {}
+    for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        v = [float(r["Counter_Value"]) for r in rows(os.path.join(d, sub, "**", "*counter_collection.csv"))
+             if "k_bounce" in r["Kernel_Name"] and r["Counter_Name"] == name]
+        if not v:
+            return
+        vals[name] = sum(v) / len(v) * 1024.0
+    with open(out_path, "w") as f:
+        json.dump({"kernel": "k_bounce", "fetch_bytes_per_launch": vals["FETCH_SIZE"], "write_bytes_per_launch": vals["WRITE_SIZE"],
+                   "launch": "bench.py default: 512^3, 1920x1080, 64 seeds in one launch",
+                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/profile_gpu.sh"}, f)
+
+
 if __name__ == "__main__":
     main(sys.argv[1])
+    if len(sys.argv) > 2:
+        traffic_json(sys.argv[1], sys.argv[2])
