@@ -14,7 +14,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libclwhip.so")
 
-SOURCES = ["clwh_runtime.hip", "render_kernels.hip", "sdf_kernels.hip", "volume_kernels.hip", "tf_parse.cpp"]
+SOURCES = ["clwh_runtime.hip", "render_kernels.hip", "sdf_kernels.hip", "volume_kernels.hip", "tf_parse.cpp", "tf_jit.cpp"]
 HEADERS = ["clwh_internal.hpp", "device_math.hpp", "render_device.hpp", "packed_volume.hpp", "env_fast.hpp"]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -67,7 +67,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     extra = os.environ.get("CLVR_EXTRA_HIPCC_FLAGS", "").split()
-    cmd = [HIPCC] + FLAGS + extra + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    cmd = [HIPCC] + FLAGS + extra + ["-x", "hip"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB, "-lhiprtc"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

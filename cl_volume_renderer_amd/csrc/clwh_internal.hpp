@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
+#include <memory>
+#include <string>
 #include <vector>
 
 #include "../../include/clwh.h"
@@ -20,7 +23,7 @@ struct TfDev {
   int32_t n;
   int32_t uses_gradient;
   int32_t literal_gradient_taps;  // 1: always take the reference's 7-fetch step (test knob CLWH_TUNE_LITERAL_GRADIENT)
-  int32_t pad_;
+  int32_t opaque;                 // 1: classes come from a hiprtc-compiled is_event_gen (tf_jit.cpp); rules hold only colours
   TfRuleDev rules[CLWH_TF_MAX_RULES];
 };
 
@@ -90,6 +93,7 @@ struct RepackArgs {
   int32_t NBX, NBY, NBZ;
   uint32_t *packed;
   uint8_t *stepb;
+  const uint8_t *cls_in;   // opaque TF: class byte per voxel (linear), computed by the JIT classifier
   TfDev tf;
 };
 
@@ -104,7 +108,17 @@ struct SdfArgs {
   int32_t *counters;   // [layer] write counts
   int32_t *done;       // [layer] early-out chain (fused build only; nullptr for the generic launch)
   int32_t *counter_out;  // generic launch: the caller's `add_buffer`
+  const uint8_t *cls_in; // opaque TF: class byte per voxel (linear)
   TfDev tf;
+};
+
+// hiprtc fallback for TF source outside the rule grammar (tf_jit.cpp)
+int tf_jit_compile(const char *user_source, std::vector<char> &code, std::string &log);
+struct JitTf {
+  std::string source;
+  std::vector<char> code;
+  hipModule_t module = nullptr;
+  hipFunction_t classify = nullptr;
 };
 
 // host-side launchers implemented in the .hip files
@@ -158,6 +172,15 @@ struct clwh_ctx {
   size_t fixups_bytes = 0;
   unsigned long long *delta = nullptr;
   size_t delta_bytes = 0;
+  // hiprtc-compiled transfer functions, by source text; and the class bytes of the current (volume, source)
+  std::map<std::string, std::shared_ptr<clvr::JitTf>> jit_cache;
+  uint8_t *jit_cls = nullptr;
+  size_t jit_cls_bytes = 0;
+  unsigned long long *jit_palette = nullptr;  // CLWH_TF_MAX_RULES keys + 1 error word
+  const void *jit_vol = nullptr;
+  uint64_t jit_vol_ver = 0;
+  std::string jit_source;
+  clvr::TfDev jit_tf{};
   bool fixup_overflow_pending = false;
   // measured on MI355X (profiles/r01_tune_*.txt): a wave that runs its 64 samples to completion with
   // steps and events in separate wave-wide phases beats mid-flight refills (12.5 vs 7.6 Gsamples/s)
@@ -223,4 +246,5 @@ struct clwh_kernel {
   int id = CLWH_K_EMPTY;
   clwh_tf tf{};
   bool has_tf = false;
+  std::shared_ptr<clvr::JitTf> jit;  // set when the source is outside the rule grammar
 };

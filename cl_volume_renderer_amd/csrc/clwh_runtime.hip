@@ -56,6 +56,84 @@ static void tf_to_dev(const clwh_tf &tf, TfDev &d) {
   }
 }
 
+// ---- hiprtc fallback (tf_jit.cpp): compile once per source text and context
+static int jit_for_source(clwh_ctx *ctx, const char *source, std::shared_ptr<JitTf> &out) {
+  auto it = ctx->jit_cache.find(source);
+  if (it != ctx->jit_cache.end()) {
+    out = it->second;
+    return CLWH_OK;
+  }
+  auto j = std::make_shared<JitTf>();
+  j->source = source;
+  std::string log;
+  const int rc = tf_jit_compile(source, j->code, log);
+  if (rc != CLWH_OK) {
+    if (!log.empty()) std::fprintf(stderr, "clwhip: transfer-function source is neither in the rule grammar nor compilable:\n%s\n", log.c_str());
+    return rc;
+  }
+  ctx->jit_cache[source] = j;
+  out = j;
+  return CLWH_OK;
+}
+
+// class byte per voxel + colour palette of an opaque TF for `volume`; cached per (volume content, source)
+static int ensure_classes(clwh_ctx *ctx, const std::shared_ptr<JitTf> &jit, const clwh_mem *volume, TfDev &tf_out,
+                          const uint8_t **cls_out) {
+  if (ctx->jit_cls && ctx->jit_vol == volume->dptr && ctx->jit_vol_ver == volume->version && ctx->jit_source == jit->source) {
+    tf_out = ctx->jit_tf;
+    *cls_out = ctx->jit_cls;
+    return CLWH_OK;
+  }
+  if (!jit->module) {
+    HIP_TRY(hipModuleLoadData(&jit->module, jit->code.data()));
+    HIP_TRY(hipModuleGetFunction(&jit->classify, jit->module, "clvr_tf_classify"));
+  }
+  const size_t voxels = volume->dims[0] * volume->dims[1] * volume->dims[2];
+  if (ctx->jit_cls_bytes < voxels) {
+    if (ctx->jit_cls) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      HIP_TRY(hipFree(ctx->jit_cls));
+      ctx->jit_cls = nullptr;
+      ctx->jit_cls_bytes = 0;
+    }
+    HIP_TRY(hipMalloc((void **)&ctx->jit_cls, voxels));
+    ctx->jit_cls_bytes = voxels;
+  }
+  constexpr int kColors = CLWH_TF_MAX_RULES;
+  if (!ctx->jit_palette) HIP_TRY(hipMalloc((void **)&ctx->jit_palette, (kColors + 1) * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(ctx->jit_palette, 0xFF, kColors * sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->jit_palette + kColors, 0, sizeof(unsigned long long), ctx->stream));
+  const void *vol = volume->dptr;
+  int X = (int)volume->dims[0], Y = (int)volume->dims[1], Z = (int)volume->dims[2], max_colors = kColors;
+  unsigned char *cls = ctx->jit_cls;
+  unsigned long long *palette = ctx->jit_palette;
+  int *error = reinterpret_cast<int *>(ctx->jit_palette + kColors);
+  void *args[] = {&vol, &X, &Y, &Z, &cls, &palette, &max_colors, &error};
+  const size_t blocks = (voxels + 255u) / 256u;
+  if (blocks > 0x7fffffffu) return CLWH_ERR_INVALID_VALUE;
+  HIP_TRY(hipModuleLaunchKernel(jit->classify, (unsigned)blocks, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
+  unsigned long long host[kColors + 1];
+  HIP_TRY(hipMemcpyAsync(host, ctx->jit_palette, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  ctx->jit_vol = nullptr;  // invalid until fully built
+  if ((int)(host[kColors] & 0xFFFFFFFFull) != 0) return CLWH_ERR_TF_UNSUPPORTED;  // more distinct colours than the table holds
+  TfDev t;
+  std::memset(&t, 0, sizeof t);
+  t.opaque = 1;
+  for (int k = 0; k < kColors && host[k] != ~0ull; ++k) {
+    t.rules[k].flags = (host[k] >> 32) & 1ull ? TF_WRITES_COLOR : 0u;
+    t.rules[k].color = (uint32_t)(host[k] & 0xFFFFFFFFull);
+    t.n = k + 1;
+  }
+  ctx->jit_tf = t;
+  ctx->jit_vol = volume->dptr;
+  ctx->jit_vol_ver = volume->version;
+  ctx->jit_source = jit->source;
+  tf_out = t;
+  *cls_out = ctx->jit_cls;
+  return CLWH_OK;
+}
+
 extern "C" {
 
 // ------------------------------------------------------------------------------------------------
@@ -112,6 +190,10 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
   if (ctx->render_counters) (void)hipFree(ctx->render_counters);
   if (ctx->fixups) (void)hipFree(ctx->fixups);
   if (ctx->delta) (void)hipFree(ctx->delta);
+  if (ctx->jit_cls) (void)hipFree(ctx->jit_cls);
+  if (ctx->jit_palette) (void)hipFree(ctx->jit_palette);
+  for (auto &kv : ctx->jit_cache)
+    if (kv.second->module) (void)hipModuleUnload(kv.second->module);
   if (ctx->sdf_counters) (void)hipFree(ctx->sdf_counters);
   if (ctx->sdf_flags) (void)hipFree(ctx->sdf_flags);
   if (ctx->packed) (void)hipFree(ctx->packed);
@@ -333,6 +415,7 @@ int clwh_kernel_get(clwh_ctx *ctx, const char *file, const char *entry, const ch
   }
   if (have_src && needs_tf) {
     int rc = clwh_tf_parse(prepend, &k->tf);
+    if (rc == CLWH_ERR_TF_UNSUPPORTED) rc = jit_for_source(ctx, prepend, k->jit);  // general fallback: hiprtc
     if (rc != CLWH_OK) {
       delete k;
       return rc;
@@ -367,7 +450,7 @@ static bool is_image(const clwh_mem *m, int dims_n, int channels, int elem_kind)
 }
 
 // (re)build the packed {value, sdf, class} records when the volume, the SDF or the TF changed
-static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *sdf, const TfDev &tf) {
+static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *sdf, const TfDev &tf, const uint8_t *cls_in) {
   const int X = (int)volume->dims[0], Y = (int)volume->dims[1], Z = (int)volume->dims[2];
   const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 7) / 8;
   const size_t records = (size_t)NBX * NBY * NBZ * 512u;
@@ -395,6 +478,7 @@ static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *
   r.NBX = NBX; r.NBY = NBY; r.NBZ = NBZ;
   r.packed = ctx->packed;
   r.stepb = reinterpret_cast<uint8_t *>(ctx->packed + records);
+  r.cls_in = cls_in;
   r.tf = tf;
   HIP_TRY(launch_repack(r, ctx->stream));
   ctx->packed_vol = volume->dptr;
@@ -500,7 +584,14 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     a.n_seeds = 1;
     a.seeds[0] = d->seed;
   }
-  tf_to_dev(k->tf, a.tf);
+  const uint8_t *cls_in = nullptr;
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (k->jit) {
+    int jrc = ensure_classes(ctx, k->jit, d->volume, a.tf, &cls_in);
+    if (jrc != CLWH_OK) return jrc;
+  } else {
+    tf_to_dev(k->tf, a.tf);
+  }
   a.tf.literal_gradient_taps = ctx->tune_literal_gradient;
   a.step_min_lanes = ctx->tune_step_min_lanes;
   a.bounce_max_blocks = ctx->tune_bounce_max_blocks;
@@ -509,7 +600,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   a.unit_queues = ctx->tune_unit_queues;
 
   HIP_TRY(hipSetDevice(ctx->device));
-  int rc = ensure_packed(ctx, d->volume, d->sdf, a.tf);
+  int rc = ensure_packed(ctx, d->volume, d->sdf, a.tf, cls_in);
   if (rc != CLWH_OK) return rc;
   a.packed = ctx->packed;
   a.NBX = (a.X + 7) / 8;
@@ -634,11 +725,20 @@ int clwh_sdf_build(clwh_ctx *ctx, clwh_mem *volume, const char *tf_source, clwh_
   for (int q = 0; q < 3; ++q)
     if (volume->dims[q] != sdf->dims[q]) return CLWH_ERR_SIZE_MISMATCH;
   if (volume->dims[1] > 65535 || volume->dims[2] > 65535) return CLWH_ERR_INVALID_VALUE;
+  HIP_TRY(hipSetDevice(ctx->device));
   clwh_tf tf;
+  TfDev tfdev;
+  const uint8_t *cls_in = nullptr;
   int rc = clwh_tf_parse(tf_source, &tf);
+  if (rc == CLWH_OK) {
+    tf_to_dev(tf, tfdev);
+  } else if (rc == CLWH_ERR_TF_UNSUPPORTED) {
+    std::shared_ptr<JitTf> jit;
+    rc = jit_for_source(ctx, tf_source, jit);
+    if (rc == CLWH_OK) rc = ensure_classes(ctx, jit, volume, tfdev, &cls_in);
+  }
   if (rc != CLWH_OK) return rc;
 
-  HIP_TRY(hipSetDevice(ctx->device));
   const int X = (int)volume->dims[0], Y = (int)volume->dims[1], Z = (int)volume->dims[2];
   const int TX = (X + 7) / 8, TY = (Y + 7) / 8, TZ = (Z + 7) / 8;
   const size_t n_tiles = (size_t)TX * TY * TZ;
@@ -655,8 +755,9 @@ int clwh_sdf_build(clwh_ctx *ctx, clwh_mem *volume, const char *tf_source, clwh_
   b.X = X; b.Y = Y; b.Z = Z;
   b.ping = (int8_t *)sdf->dptr;
   b.max_iterations = sdf_max_iterations(volume);
-  b.counters = ctx->sdf_counters;  // [0] = number of |v| == 1 voxels
-  tf_to_dev(tf, b.tf);
+  b.counters = ctx->sdf_counters;  // [0] != 0: some |v| == 1
+  b.tf = tfdev;
+  b.cls_in = cls_in;
   uint8_t *flags[3] = {ctx->sdf_flags, ctx->sdf_flags + n_tiles, ctx->sdf_flags + 2 * n_tiles};
   HIP_TRY(launch_sdf_base_front(b, flags[1], TX, TY, ctx->stream));  // layer 1 reads flags[1 % 3]
 
@@ -855,7 +956,12 @@ int clwh_launch(clwh_kernel *k, const size_t global_in[3], const size_t local_in
       a.ping = (int8_t *)ping->dptr;
       a.pong = (int8_t *)pong->dptr;
       a.max_iterations = max_it;
-      tf_to_dev(k->tf, a.tf);
+      if (k->jit) {
+        int jrc = ensure_classes(ctx, k->jit, v, a.tf, &a.cls_in);
+        if (jrc != CLWH_OK) return jrc;
+      } else {
+        tf_to_dev(k->tf, a.tf);
+      }
       HIP_TRY(launch_sdf_base(a, ctx->stream));
       touch(ping);
       touch(pong);

@@ -155,7 +155,7 @@ __device__ __forceinline__ bool taps_are_voxel_neighbours(f3 p) {
 // otherwise `next_sd` is the SDF value for the next step
 template <bool USE_GRAD>
 __device__ __forceinline__ bool classify_step(const VolumePacked &v, const TfDev &tf, f3 pos, uint32_t &color, int &next_sd) {
-  if (USE_GRAD && (tf.literal_gradient_taps || !taps_are_voxel_neighbours(pos))) {
+  if (USE_GRAD && !tf.opaque && (tf.literal_gradient_taps || !taps_are_voxel_neighbours(pos))) {
     const uint32_t r = v.fetch_f(pos.x, pos.y, pos.z);
     const int gradient = (int)(short)f2i(length3(gradient_nn(v, pos)));
     next_sd = VolumePacked::sdf_of(r) > 0 ? VolumePacked::sdf_of(r) : 0;

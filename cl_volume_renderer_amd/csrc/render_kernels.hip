@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
       gradient = (int)(short)f2i(sqrtf((gx * gx + gy * gy) + gz * gz));
     }
     // class = 1 + index of the first matching rule; a terminal rule (`return (cond);`) ends the evaluation
-    unsigned cls = 0u;
-    for (int k = 0; k < a.tf.n; ++k) {
+    unsigned cls = a.cls_in ? a.cls_in[i] : 0u;
+    for (int k = 0; k < a.tf.n && !a.cls_in; ++k) {
       const TfRuleDev &rule = a.tf.rules[k];
       bool m = value >= rule.v_lo && value <= rule.v_hi;
       if (rule.flags & TF_USE_GRADIENT) m = m && gradient >= rule.g_lo && gradient <= rule.g_hi;

@@ -23,7 +23,8 @@ struct VolumeIntLinear {
 };
 
 template <bool USE_GRAD>
-__device__ __forceinline__ bool event_at(const VolumeIntLinear &v, const TfDev &tf, int x, int y, int z) {
+__device__ __forceinline__ bool event_at(const VolumeIntLinear &v, const TfDev &tf, const uint8_t *cls_in, int x, int y, int z) {
+  if (cls_in) return cls_in[((size_t)z * (size_t)v.Y + (size_t)y) * (size_t)v.X + (size_t)x] != 0;  // opaque TF (tf_jit.cpp)
   const int value = v.at(x, y, z);
   int gradient = 0;
   if (USE_GRAD) {
@@ -45,14 +46,14 @@ __global__ __launch_bounds__(256) void k_sdf_base(const SdfArgs a) {
   const int z = blockIdx.z;
   if (x >= a.X) return;
   const VolumeIntLinear v{a.volume, a.X, a.Y, a.Z};
-  const bool e = event_at<USE_GRAD>(v, a.tf, x, y, z);
+  const bool e = event_at<USE_GRAD>(v, a.tf, a.cls_in, x, y, z);
   bool homogenous = true;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int nx = min(max(x + ((c & 1) ? 1 : -1), 0), a.X - 1);
     const int ny = min(max(y + ((c & 2) ? 1 : -1), 0), a.Y - 1);
     const int nz = min(max(z + ((c & 4) ? 1 : -1), 0), a.Z - 1);
-    homogenous &= (event_at<USE_GRAD>(v, a.tf, nx, ny, nz) == e);
+    homogenous &= (event_at<USE_GRAD>(v, a.tf, a.cls_in, nx, ny, nz) == e);
   }
   int r = e ? -1 : 1;
   if (homogenous) r *= a.max_iterations;
@@ -134,14 +135,14 @@ __global__ __launch_bounds__(256) void k_sdf_base_front(const SdfArgs a, uint8_t
   bool is_one = false;
   if (x < a.X) {
     const VolumeIntLinear v{a.volume, a.X, a.Y, a.Z};
-    const bool e = event_at<USE_GRAD>(v, a.tf, x, y, z);
+    const bool e = event_at<USE_GRAD>(v, a.tf, a.cls_in, x, y, z);
     bool homogenous = true;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int nx = min(max(x + ((c & 1) ? 1 : -1), 0), a.X - 1);
       const int ny = min(max(y + ((c & 2) ? 1 : -1), 0), a.Y - 1);
       const int nz = min(max(z + ((c & 4) ? 1 : -1), 0), a.Z - 1);
-      homogenous &= (event_at<USE_GRAD>(v, a.tf, nx, ny, nz) == e);
+      homogenous &= (event_at<USE_GRAD>(v, a.tf, a.cls_in, nx, ny, nz) == e);
     }
     int r = e ? -1 : 1;
     if (homogenous) r *= a.max_iterations;

@@ -35,7 +35,7 @@ enum clwh_status {
   CLWH_ERR_OUT_OF_MEMORY = 3,
   CLWH_ERR_HIP = 4,            /* a HIP runtime call failed; clwh_last_hip_error() has the code */
   CLWH_ERR_UNKNOWN_KERNEL = 5, /* (file, entry) is not one of the precompiled hot-path kernels */
-  CLWH_ERR_TF_UNSUPPORTED = 6, /* the prepended transfer-function source is outside the grammar */
+  CLWH_ERR_TF_UNSUPPORTED = 6, /* the transfer-function source neither parses as rules nor compiles with hiprtc */
   CLWH_ERR_BAD_ARGS = 7,       /* wrong number / kind of kernel arguments */
   CLWH_ERR_BAD_NDRANGE = 8,    /* global not a multiple of local, zero size, ... */
   CLWH_ERR_SIZE_MISMATCH = 9,
@@ -90,7 +90,9 @@ int clwh_mem_mark_dirty(clwh_mem *mem);
  * clwh_kernel_get replaces clw_function's ctor (clw_function.hpp:74-111): instead of flattening
  * `#clw_include_once`, prepending `prepend` and JIT-compiling, it looks (file, entry) up in the
  * registry of precompiled HIP kernels and parses `prepend` (the generated `is_event_gen` source,
- * app/ui.cpp:160-168) into a rule table that becomes a launch-time parameter.
+ * app/ui.cpp:160-168) into a rule table that becomes a launch-time parameter; source outside the rule
+ * grammar is compiled with hiprtc into a per-voxel classifier (csrc/tf_jit.cpp), so any `is_event_gen`
+ * the reference's JIT would accept is accepted here too (up to 16 distinct colours).
  * Known pairs: ("ray_marching.cl","render"), ("signed_distance_field.cl","create_base_image"),
  * ("signed_distance_field.cl","create_signed_distance_field"), ("buffer_reset.cl","buffer_reset"),
  * ("empty.cl","empty"), and next to the hot path ("reference_volume_figures.cl","fetch_stats"),

@@ -311,3 +311,54 @@ def test_released_and_reallocated_images_do_not_alias_derived_data(orc):
     # informational: on this allocator the second pair normally reuses the first pair's addresses
     print("device addresses", addresses)
     ctx.destroy()
+
+
+FREE_FORM_TF = ("inline bool is_event_gen(short value, short gradient, int4 *color){\n"
+                "  if (value > 800 || value < -1010) {\n    int4 tmp_color = {200,100,50,255};\n    *color = tmp_color;\n"
+                "    return true;\n  }\n  if (value >= 30 && value <= 45) { int4 c2 = {20,220,120,128}; *color = c2; return true; }\n"
+                "  return false;\n}\n")
+
+
+def _free_form_tf_as_rules(orc):
+    """the same function as first-match rules, for the oracle (its table cannot say `||`)"""
+    tf = orc.Tf()
+    spec = [(801, 32767, (200, 100, 50, 255)), (-32768, -1011, (200, 100, 50, 255)), (30, 45, (20, 220, 120, 128))]
+    for k, (lo, hi, col) in enumerate(spec):
+        r = tf.rules[k]
+        r.v_lo, r.v_hi, r.g_lo, r.g_hi = lo, hi, -32768, 32767
+        r.use_gradient, r.writes_color, r.terminal = 0, 1, 0
+        for q in range(4):
+            r.color[q] = col[q]
+    tf.n = len(spec)
+    return tf
+
+
+def test_free_form_tf_source_goes_through_hiprtc(gpu_ctx, orc):
+    """source outside the rule grammar (`||`, a differently named temporary) is compiled with hiprtc into the
+    per-voxel classifier ("hiprtc as the general fallback"); SDF, cache and frame stay bit-exact."""
+    with pytest.raises(ffi.ClwhError):
+        ffi.parse_tf(FREE_FORM_TF)                      # the rule parser refuses it ...
+    rules = _free_form_tf_as_rules(orc)
+    vol = scene.phantom(48)
+    env = scene.env_map(256, 128)
+    want_sdf, n_want, _ = orc.sdf_build(vol, rules)
+    g = GpuScene(gpu_ctx, vol, None, env, FREE_FORM_TF, (160, 128))   # ... clwh_kernel_get compiles it
+    assert gpu_ctx.sdf_build(g.volume, FREE_FORM_TF, g.sdf) == n_want
+    assert np.array_equal(g.sdf.pull(), want_sdf)
+    pos, d = look_at_centre(vol, [-20, 40, -20])
+    o = orc.Scene(vol, want_sdf, env, rules, (160, 128))
+    for s in scene.glibc_rand(3):
+        g.render(pos, d, s)
+        o.render(pos, d, s)
+        assert np.array_equal(g.contrib.pull(), o.contrib)
+    assert (o.hit_index >= 0).sum() > 3000
+    assert np.array_equal(g.cache.pull(), o.cache)
+    o.resolve(pos, d)
+    assert np.array_equal(g.frame.pull(), o.frame)
+    g.release()
+
+
+def test_uncompilable_tf_source_is_refused(gpu_ctx):
+    with pytest.raises(ffi.ClwhError) as e:
+        gpu_ctx.kernel("ray_marching.cl", "render", "inline bool is_event_gen(short value, short gradient, int4 *color){ return undefined_symbol(value); }")
+    assert e.value.status == 6  # CLWH_ERR_TF_UNSUPPORTED
