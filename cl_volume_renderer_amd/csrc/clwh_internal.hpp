@@ -137,6 +137,7 @@ struct SdfFrontArgs {
   const uint8_t *flags_cur;   // tiles that settled voxels in the previous layer (or hold |v| == 1 for layer 1)
   uint8_t *flags_next;        // tiles that settle voxels in this layer
   uint8_t *flags_clear;       // third buffer, zeroed here for the layer after next
+  uint8_t *tile_done;         // 1: every voxel of the tile is settled, the tile is never visited again
   int32_t iteration;
   int32_t max_iterations;
   int32_t *counters;          // [i] != 0: layer i settled a voxel to a value < max_iterations; [0] != 0: some |v| == 1
@@ -199,7 +200,7 @@ struct clwh_ctx {
   } primary_key{};
   uint64_t packed_generation = 0;
   int32_t *sdf_counters = nullptr;  // 160 ints: settled voxels per layer
-  uint8_t *sdf_flags = nullptr;     // 3 x tiles bytes (current / next / being cleared)
+  uint8_t *sdf_flags = nullptr;     // 4 x tiles bytes (current / next / being cleared / done)
   size_t sdf_flags_bytes = 0;
   // derived packed volume (single entry, keyed by the source objects' identity + version and the TF)
   uint32_t *packed = nullptr;

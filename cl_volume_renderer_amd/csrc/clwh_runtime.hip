@@ -742,12 +742,12 @@ int clwh_sdf_build(clwh_ctx *ctx, clwh_mem *volume, const char *tf_source, clwh_
   const int X = (int)volume->dims[0], Y = (int)volume->dims[1], Z = (int)volume->dims[2];
   const int TX = (X + 7) / 8, TY = (Y + 7) / 8, TZ = (Z + 7) / 8;
   const size_t n_tiles = (size_t)TX * TY * TZ;
-  rc = grow(ctx, (void **)&ctx->sdf_flags, &ctx->sdf_flags_bytes, 3 * n_tiles);
+  rc = grow(ctx, (void **)&ctx->sdf_flags, &ctx->sdf_flags_bytes, 4 * n_tiles);
   if (rc != CLWH_OK) return rc;
   constexpr int kSlots = 160;
   if (!ctx->sdf_counters) HIP_TRY(hipMalloc((void **)&ctx->sdf_counters, kSlots * sizeof(int32_t)));
   HIP_TRY(hipMemsetAsync(ctx->sdf_counters, 0, kSlots * sizeof(int32_t), ctx->stream));
-  HIP_TRY(hipMemsetAsync(ctx->sdf_flags, 0, 3 * n_tiles, ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->sdf_flags, 0, 4 * n_tiles, ctx->stream));
 
   SdfArgs b;
   std::memset(&b, 0, sizeof b);
@@ -768,6 +768,7 @@ int clwh_sdf_build(clwh_ctx *ctx, clwh_mem *volume, const char *tf_source, clwh_
   a.TX = TX; a.TY = TY; a.TZ = TZ;
   a.max_iterations = b.max_iterations;
   a.counters = ctx->sdf_counters;
+  a.tile_done = ctx->sdf_flags + 3 * n_tiles;
 
   // layers that can still settle a voxel: i + 1 < max_iterations; the host looks at the per-layer
   // counts every 16 launches and stops once a layer settled nothing (nothing can change after it)

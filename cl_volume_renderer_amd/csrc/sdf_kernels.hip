@@ -190,7 +190,9 @@ __global__ __launch_bounds__(256) void k_sdf_front(const SdfFrontArgs a) {
     bool active = false;
     if (tile < n_tiles) {
       a.flags_clear[tile] = 0;
-      active = a.flags_cur[tile] != 0;  // set by whoever settled a voxel next to (or inside) this tile
+      // flagged by whoever settled a voxel next to (or inside) this tile -- unless every voxel of the tile
+      // is settled already (the front has passed): such a tile can never change again
+      active = a.flags_cur[tile] != 0 && a.tile_done[tile] == 0;
     }
     const unsigned long long am = __ballot(active);
     if (active) s_list[__builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0u))] = tile;
@@ -232,6 +234,7 @@ __global__ __launch_bounds__(256) void k_sdf_front(const SdfFrontArgs a) {
     }
     __syncthreads();
     int settled = 0;
+    bool open_voxels = false;  // does this lane still hold a voxel that may settle in a later layer?
     unsigned face_mask = 0u;  // which faces of the tile this lane's settled voxels lie on: -x +x -y +y -z +z
     if (have) {
       const int ly = (int)(lane & 7u), lz = (int)(lane >> 3);
@@ -243,6 +246,7 @@ __global__ __launch_bounds__(256) void k_sdf_front(const SdfFrontArgs a) {
         for (int lx = 0; lx < 8; ++lx) {
           if (x0 + lx >= a.X) break;
           const int v = c[lx];
+          bool still_open = abs(v) > it + 1;
           if (abs(v) > it) {
             int nd = 127, abs_added = 0, added = 0;
 #pragma unroll
@@ -258,13 +262,16 @@ __global__ __launch_bounds__(256) void k_sdf_front(const SdfFrontArgs a) {
               // the reference only writes (and counts) values below max_iterations; +-max stays as it is
               out[lx] = (int8_t)(v < 0 ? -(it + 1) : (it + 1));
               ++settled;
+              still_open = false;
               face_mask |= (lx == 0 ? 1u : 0u) | (lx == 7 ? 2u : 0u) | (ly == 0 ? 4u : 0u) | (ly == 7 ? 8u : 0u) |
                            (lz == 0 ? 16u : 0u) | (lz == 7 ? 32u : 0u);
             }
           }
+          open_voxels |= still_open;
         }
       }
     }
+    if (have && __ballot(open_voxels) == 0ull && lane == 0u) a.tile_done[t] = 1;
     // per wave: count, and flag every tile that holds a corner neighbour of a voxel settled here: the
     // tile itself and the (up to 26) neighbours its settled boundary voxels touch
     const unsigned long long sm = __ballot(settled > 0);
