@@ -1,0 +1,83 @@
+"""-m gpu: degenerate and adversarial inputs through the C ABI against the oracle: tiny volumes and frames,
+zero-gradient hits (NaN normals: normalize(0), SURVEY "hard parts"), random multi-rectangle transfer functions."""
+import numpy as np
+import pytest
+
+from cl_volume_renderer_amd import ffi, scene
+from tests.gpu_util import GpuScene, look_at_centre
+
+pytestmark = pytest.mark.gpu
+
+
+def _parity(orc, ctx, vol, env, tf, frame_wh, pos, d, seeds, mode="voxel"):
+    sdf, _, _ = orc.sdf_build(vol, orc.parse_tf(tf))
+    g = GpuScene(ctx, vol, None, env, tf, frame_wh)
+    ctx.sdf_build(g.volume, tf, g.sdf)
+    assert np.array_equal(g.sdf.pull(), sdf)
+    omode = orc.MODE_VOXEL_CACHE if mode == "voxel" else orc.MODE_IMAGE_SPACE
+    gmode = ffi.ACCUM_VOXEL_CACHE if mode == "voxel" else ffi.ACCUM_IMAGE_SPACE
+    o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), frame_wh, mode=omode)
+    for s in seeds:
+        g.render(pos, d, s, mode=gmode)
+        o.render(pos, d, s)
+        assert np.array_equal(g.hit_index.pull(), o.hit_index)
+        assert np.array_equal(g.contrib.pull(), o.contrib)
+    if mode == "voxel":
+        assert np.array_equal(g.cache.pull(), o.cache)
+    else:
+        hit = o.hit_index.reshape(frame_wh[1], frame_wh[0]) >= 0
+        assert np.array_equal(g.accum_row_major(0)[hit], o.accum[hit])
+    o.resolve(pos, d)
+    assert np.array_equal(g.frame.pull(), o.frame)
+    hits = int((o.hit_index >= 0).sum())
+    g.release()
+    return hits
+
+
+@pytest.mark.parametrize("dims", [(2, 2, 2), (3, 2, 5), (9, 5, 3), (16, 1, 16)])
+def test_tiny_volumes_and_frames(gpu_ctx, orc, dims):
+    """the reference's placeholder SDF is 2x2x2 (signed_distance_field.cpp:43-45); max_iterations is 0 or 1 here"""
+    X, Y, Z = dims
+    rng = np.random.default_rng(X * 100 + Y * 10 + Z)
+    vol = rng.integers(400, 1400, size=(Z, Y, X), dtype=np.int16)
+    env = scene.env_map(4, 2)
+    pos = np.array([-3.0, Y + 4.0, -2.5], np.float32)
+    _, d = look_at_centre(vol, pos)
+    _parity(orc, gpu_ctx, vol, env, scene.tf_default_source(), (8, 8), pos, d, [1, 2, 3])
+    _parity(orc, gpu_ctx, vol, env, scene.tf_default_source(), (16, 8), pos, d, [5], mode="image")
+
+
+def test_zero_gradient_hits_give_nan_normals_like_the_oracle(gpu_ctx, orc):
+    """piecewise-constant volume: hits inside constant blocks have a zero central-difference gradient, so
+    normal = -normalize(0) = NaN; the NaN ray never exits and contributes nothing (ray_marching.cl:42,64;
+    utility_ray.cl:114-116).  Both sides must agree bit for bit on what that does to the cache."""
+    rng = np.random.default_rng(77)
+    coarse = rng.choice(np.array([-1000, 700, 900, 1100, 40], np.int16), size=(8, 8, 8))
+    vol = np.ascontiguousarray(np.kron(coarse, np.ones((6, 6, 6), np.int16)).astype(np.int16))   # 48^3, 6^3 blocks
+    env = scene.env_map(64, 32)
+    pos, d = look_at_centre(vol, [-15, 30, -20])
+    hits = _parity(orc, gpu_ctx, vol, env, scene.tf_default_source(), (128, 96), pos, d, scene.glibc_rand(3))
+    assert hits > 3000
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_random_rectangle_transfer_functions(gpu_ctx, orc, case):
+    """1-3 overlapping rectangles with random value / gradient windows, colours and roughness: first match
+    wins, gradient clauses are baked or evaluated literally, colours carry over between distribution rays."""
+    rng = np.random.default_rng(1000 + case)
+    rects = []
+    for _ in range(int(rng.integers(1, 4))):
+        lo = float(rng.integers(-1100, 1000))
+        hi = lo + float(rng.integers(20, 900))
+        if rng.random() < 0.5:
+            glo, ghi = float(rng.integers(0, 400)), float(rng.integers(600, 3999))
+        else:
+            glo, ghi = 0.0, 4000.0
+        rects.append((lo + 0.5 * float(rng.integers(0, 2)), hi, glo, ghi, tuple(float(x) for x in rng.random(4))))
+    tf = scene.tf_rect_source(rects)
+    vol = scene.phantom(40, seed=case)
+    vol[5:15, 20:30, 8:30] = 300                      # a second, flat material
+    env = scene.env_map(128, 64, seed=case)
+    pos, d = look_at_centre(vol, [float(rng.integers(-30, -5)), float(rng.integers(20, 60)), float(rng.integers(-30, -5))])
+    _parity(orc, gpu_ctx, vol, env, tf, (96, 64), pos, d, scene.glibc_rand(2))
+    _parity(orc, gpu_ctx, vol, env, tf, (96, 64), pos, d, [int(rng.integers(0, 2**31 - 1))], mode="image")
