@@ -73,6 +73,63 @@ def voxel_cache_bytes(c, samples):
             + 8 * c["n_read"] + 4 * samples) / float(samples)
 
 
+def run_voxel_mode(args, ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, seeds, N, W, H, rank, world, dev, barrier,
+                   sdf_build_s, n_layers):
+    """Reference-exact accumulation: every rank renders its image tiles into a private world-space cache
+    (token cap on, one pass per launch as renderer::render_frame does), then ONE all-reduce(SUM) of the
+    caches (tiles.reduce_voxel_caches) and a resolve of the rank's tiles."""
+    import torch
+    import torch.distributed as dist
+
+    from cl_volume_renderer_amd import ffi, tiles
+
+    n_cache = ffi.cache_len(N, N, N)
+    cache = torch.zeros(n_cache // 2, dtype=torch.int32, device=dev)
+    m_cache = ctx.wrap(cache.data_ptr(), n_cache * 2)
+
+    def one_pass(seed, write_frame):
+        kernel.render(frame=d_frame, volume=d_vol, sdf=d_sdf, env=d_env, buffer_volume=m_cache, cam_pos=pos, cam_dir=cdir,
+                      seed=seed, width=W, height=H, mode=ffi.ACCUM_VOXEL_CACHE, tile_rank=rank, tile_world=world,
+                      write_frame=write_frame)
+
+    for s in seeds[: args.warmup]:
+        one_pass(s, False)
+    tiles.reduce_voxel_caches(cache, world)  # untimed: channel set-up
+    cache.zero_()
+    ctx.invalidate_derived(scene=False, camera=True)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in seeds[args.warmup:]:
+        one_pass(s, False)
+    tiles.reduce_voxel_caches(cache, world)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    counts = (cache.view(-1, 2)[:, 1] >> 16) & 0xFFFF
+    if rank == 0:
+        print(json.dumps({
+            "metric": "msamples_per_sec", "value": round(W * H * args.steps / elapsed / 1e6, 3), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[%d]: %d^3 phantom, %dx%d frame, %d spp, reference-exact voxel cache" % (
+                           args.config - 1, N, W, H, args.steps),
+                       "accumulation": "world-space voxel cache per rank (token cap on), one pass per launch, "
+                                       "one all-reduce(SUM) of the caches at the end",
+                       "sdf_build_s": round(sdf_build_s, 4), "sdf_layers": n_layers,
+                       "voxels_touched": int((counts > 0).sum().item()), "max_count": int(counts.max().item())},
+        }), flush=True)
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,6 +147,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
     ap.add_argument("--no-secondary", action="store_true", help="skip the voxel-cache-mode measurement")
+    ap.add_argument("--accumulation", choices=["image", "voxel"], default="image",
+                    help="image: float4 per pixel + one all-gather (the headline); voxel: the reference's world-space "
+                         "cache per rank, one pass per launch, + one all-reduce of the caches (exact below the token cap)")
     ap.add_argument("--seeds-per-launch", type=int, default=64,
                     help="render passes fused into one launch of the persistent bounce kernel (1..64)")
     args = ap.parse_args()
@@ -167,6 +227,10 @@ def main():
     m_accum_all = ctx.wrap(accum_all.data_ptr(), accum_all.numel() * 4)
 
     S = max(1, min(ffi.MAX_SEEDS, args.seeds_per_launch))
+    if args.accumulation == "voxel":
+        run_voxel_mode(args, ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, seeds, N, W, H, rank, world, dev,
+                       barrier, sdf_build_s, n_layers)
+        return
 
     def render_passes(batch):
         """len(batch) render passes (steps) in one launch of the persistent bounce kernel"""

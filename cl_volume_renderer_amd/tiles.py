@@ -67,3 +67,24 @@ def gather_accum(accum, accum_all, world: int):
         dist.all_gather_into_tensor(host_all, accum.cpu())
         accum_all.copy_(host_all)
     return accum_all
+
+
+def reduce_voxel_caches(cache_words, world: int):
+    """Reference-exact voxel-cache mode across ranks (second row): every rank keeps a private
+    world-space cache for its image tiles; the caches are summed once per job.  A cache entry is four u16
+    lanes {r, g, b, count} seen as two 32-bit words, so an all-reduce(SUM) of the words adds lane-wise as long
+    as no lane carries -- which holds exactly while the GLOBAL count of a voxel stays <= 256 (lanes <= 255 x
+    count <= 65280), the same condition under which the single-GPU cache is order-independent (SURVEY facts
+    3, 4).  Beyond the cap every rank has applied the reference's token rule to its own pixels only.
+    `cache_words`: 1-D int32 torch tensor viewing the rank's cache; reduced in place on every rank."""
+    if world == 1:
+        return cache_words
+    import torch.distributed as dist
+
+    if dist.get_backend() == "nccl" or not cache_words.is_cuda:
+        dist.all_reduce(cache_words, op=dist.ReduceOp.SUM)
+    else:  # rehearsal without RCCL (gloo): stage through the host
+        host = cache_words.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        cache_words.copy_(host)
+    return cache_words

@@ -86,3 +86,40 @@ def test_accum_len_matches_the_c_abi():
 
     for (w, h, world) in [(1920, 1080, 1), (1920, 1080, 8), (3840, 2160, 8), (64, 64, 3), (96, 64, 2)]:
         assert tiles.accum_len(w, h, world) == ffi.accum_len(w, h, world)
+
+
+def _voxel_worker(rank, port, out_path):
+    import torch
+    import torch.distributed as dist
+
+    from oracle import orc_ffi
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    vol, sdf, env, tf, pos, d = _scene(orc_ffi)
+    sc = orc_ffi.Scene(vol, sdf, env, tf, (W, H), mode=orc_ffi.MODE_VOXEL_CACHE, tile_rank=rank, tile_world=WORLD)
+    for s in scene.glibc_rand(3):
+        sc.render(pos, d, s)
+    words = torch.from_numpy(sc.cache.view(np.int32).copy())
+    tiles.reduce_voxel_caches(words, WORLD)
+    if rank == 0:
+        np.save(out_path, words.numpy().view(np.uint16))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_voxel_cache_sum_equals_single_rank(orc, tmp_path):
+    """the reference-exact world-space mode across ranks: private caches, one all-reduce(SUM) of the packed
+    words; equal to the single-rank cache while no voxel reaches the 256-token cap"""
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "cache.npy")
+    mp.spawn(_voxel_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+    summed = np.load(out)
+    vol, sdf, env, tf, pos, d = _scene(orc)
+    one = orc.Scene(vol, sdf, env, tf, (W, H))
+    for s in scene.glibc_rand(3):
+        one.render(pos, d, s)
+    assert 0 < one.cache.reshape(-1, 4)[:, 3].max() < 256
+    assert np.array_equal(summed, one.cache)
