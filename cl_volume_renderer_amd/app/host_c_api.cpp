@@ -83,6 +83,8 @@ void clvr_host_volume_stats(clvr_host *h, float out[4]) {
 void clvr_host_set_clipping(clvr_host *h, const unsigned lo[3], const unsigned hi[3]) {
   h->rv->set_clipping({lo[0], lo[1], lo[2]}, {hi[0], hi[1], hi[2]});
 }
+// the "Apply Filter" checkbox (ui.cpp:274-275)
+void clvr_host_filter(clvr_host *h) { h->rv->filter(); }
 // _create_tf (ui.cpp:151-158): the transfer-function editor's histogram texture, RGBA8, width x height
 const void *clvr_host_render_tf(clvr_host *h, unsigned width, unsigned height) { return h->rend.render_tf(width, height); }
 // nrrd_loader::load_file probe (no device involved): dims, voxel count, sum of all voxels

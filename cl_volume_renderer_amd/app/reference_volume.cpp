@@ -37,6 +37,16 @@ void reference_volume::set_clipping(std::array<size_t, 3> min, std::array<size_t
   copy.execute(get_volume_size_evenness(4), {4, 4, 4}, original_volume, cropped_volume, start, length);
 }
 
+// reference :70-80.  The move assignment at :77 does take effect: the device image of the volume becomes the
+// filtered one, while its host copy is the zero-filled staging vector of `buffer` (never pulled) -- mirrored as is.
+void reference_volume::filter() {
+  clw_image<short> &ref = is_cropped() ? cropped_volume : original_volume;
+  clw_image<short> buffer(ctx, std::vector<short>(get_volume_length(), 0), get_volume_size(), false);
+  clw_function bilateral_filter(ctx, "volume_filter.cl", "bilateral_filter");
+  bilateral_filter.execute(get_volume_size_evenness(8), {4, 4, 4}, ref, buffer);
+  ref = std::move(buffer);
+}
+
 std::array<int, 2> reference_volume::get_value_range() const {
   return {std::max(value_clip[0], value_range[0]), std::min(value_clip[1], value_range[1])};
 }

@@ -1,8 +1,7 @@
 // reference_volume.hpp -- owner of the volume image, its statistics and the size helpers every launch
 // uses (mirror of the reference's app/reference_volume.hpp / .cpp).
 // On the hot path: constructor (upload), get_volume_size*, get_volume_length, get_reference_volume.
-// Next to it: fetch_stats at construction, set_clipping (apply_clip).  The bilateral
-// `filter()` of the reference discards its result (app/reference_volume.cpp:77) and is not mirrored.
+// Next to it: fetch_stats at construction, set_clipping (apply_clip), filter (bilateral_filter).
 #pragma once
 
 #include <array>
@@ -28,6 +27,8 @@ class reference_volume {
   void set_gradient_clip(std::array<int, 2> clip) { gradient_clip = clip; }
   /// crop the volume to [min, max) -- rendering, SDF and cache then use the cropped copy
   void set_clipping(std::array<size_t, 3> min, std::array<size_t, 3> max);
+  /// 5x5x5 bilateral filter of the current (cropped or original) volume; the filtered image replaces it on the device
+  void filter();
   std::array<int, 2> get_value_range() const;
   std::array<int, 2> get_gradient_range() const;
   const std::array<size_t, 3> &get_original_volume_size() const { return volume_size; }

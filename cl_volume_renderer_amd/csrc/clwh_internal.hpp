@@ -152,6 +152,7 @@ hipError_t launch_tf_sort_values(const int16_t *vol, int X, int Y, int Z, uint32
                                  float min_v, float max_v, float min_g, float max_g, hipStream_t s);
 hipError_t launch_tf_flush_color_frame(uint32_t *color_frame, int fw, int fh, const int32_t *frame, const int32_t *lookup,
                                        int lookup_len, hipStream_t s);
+hipError_t launch_bilateral_filter(const int16_t *src, int X, int Y, int Z, int16_t *dst, const float *weights, hipStream_t s);
 hipError_t launch_apply_clip(const int16_t *src, int SX, int SY, int SZ, int16_t *dst, int DX, int DY, int DZ,
                              const uint32_t *start, const uint32_t *len, hipStream_t s);
 
@@ -199,6 +200,7 @@ struct clwh_ctx {
     uint64_t packed_generation;
   } primary_key{};
   uint64_t packed_generation = 0;
+  float *bilateral_weights = nullptr;  // 13 x 17 tap weights of the bilateral volume filter (built on first use)
   int32_t *sdf_counters = nullptr;  // 160 ints: settled voxels per layer
   uint8_t *sdf_flags = nullptr;     // 4 x tiles bytes (current / next / being cleared / done)
   size_t sdf_flags_bytes = 0;
@@ -239,7 +241,8 @@ enum clwh_kernel_id {
   CLWH_K_FETCH_STATS,
   CLWH_K_APPLY_CLIP,
   CLWH_K_TF_SORT_VALUES,
-  CLWH_K_TF_FLUSH_COLOR_FRAME
+  CLWH_K_TF_FLUSH_COLOR_FRAME,
+  CLWH_K_BILATERAL_FILTER
 };
 
 struct clwh_kernel {

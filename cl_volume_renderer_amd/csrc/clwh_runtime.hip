@@ -6,6 +6,7 @@
 // transfer-function source parsed into a launch-time table instead of being JIT-compiled.
 #include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -194,6 +195,7 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
   if (ctx->jit_palette) (void)hipFree(ctx->jit_palette);
   for (auto &kv : ctx->jit_cache)
     if (kv.second->module) (void)hipModuleUnload(kv.second->module);
+  if (ctx->bilateral_weights) (void)hipFree(ctx->bilateral_weights);
   if (ctx->sdf_counters) (void)hipFree(ctx->sdf_counters);
   if (ctx->sdf_flags) (void)hipFree(ctx->sdf_flags);
   if (ctx->packed) (void)hipFree(ctx->packed);
@@ -402,6 +404,7 @@ int clwh_kernel_get(clwh_ctx *ctx, const char *file, const char *entry, const ch
   else if (!std::strcmp(base, "reference_volume_clip.cl") && !std::strcmp(entry, "apply_clip")) { id = CLWH_K_APPLY_CLIP; }
   else if (!std::strcmp(base, "histogram.cl") && !std::strcmp(entry, "tf_sort_values")) { id = CLWH_K_TF_SORT_VALUES; }
   else if (!std::strcmp(base, "histogram.cl") && !std::strcmp(entry, "tf_flush_color_frame")) { id = CLWH_K_TF_FLUSH_COLOR_FRAME; }
+  else if (!std::strcmp(base, "volume_filter.cl") && !std::strcmp(entry, "bilateral_filter")) { id = CLWH_K_BILATERAL_FILTER; }
   if (id < 0) return CLWH_ERR_UNKNOWN_KERNEL;
   clwh_kernel *k = new (std::nothrow) clwh_kernel();
   if (!k) return CLWH_ERR_OUT_OF_MEMORY;
@@ -922,6 +925,37 @@ int clwh_launch(clwh_kernel *k, const size_t global_in[3], const size_t local_in
       HIP_TRY(launch_tf_flush_color_frame((uint32_t *)cf->dptr, (int)fw, (int)fh, (const int32_t *)fr->dptr,
                                           (const int32_t *)lk->dptr, len, ctx->stream));
       touch(cf);
+      return CLWH_OK;
+    }
+
+    case CLWH_K_BILATERAL_FILTER: {
+      // bilateral_filter(reference_volume, buffer)  volume_filter.cl:5
+      if (nargs != 2 || !is_mem(0) || !is_mem(1)) return CLWH_ERR_BAD_ARGS;
+      clwh_mem *src = args[0].v.mem, *dst = args[1].v.mem;
+      if (!is_image(src, 3, 1, CLWH_ELEM_S16) || !is_image(dst, 3, 1, CLWH_ELEM_S16)) return CLWH_ERR_BAD_ARGS;
+      if (src->dptr == dst->dptr) return CLWH_ERR_BAD_ARGS;  // a stencil cannot run in place
+      for (int q = 0; q < 3; ++q)
+        if (src->dims[q] != dst->dims[q]) return CLWH_ERR_SIZE_MISMATCH;  // the reference writes to src's coordinates
+      if (src->dims[0] > 0x7fffffffu || src->dims[1] > 8u * 65535u || src->dims[2] > 8u * 65535u) return CLWH_ERR_INVALID_VALUE;
+      if (!ctx->bilateral_weights) {
+        // utility_filter.cl:43-44,53-55: w = exp(-r2/(2 sigma_s^2) - d^2/(2 sigma_r^2)), float operands, the
+        // exponential evaluated in binary64 and rounded once.  d >= 16 must already round to zero.
+        const float sigmas = 0.6f, sigmar = 1.0f;
+        float host[13 * 17];
+        for (int r2 = 0; r2 < 13; ++r2)
+          for (int d = 0; d < 17; ++d) {
+            const float posd = ((float)r2) / (2 * sigmas * sigmas);
+            const float cold = ((float)(d * d)) / (2 * sigmar * sigmar);
+            host[r2 * 17 + d] = (float)std::exp((double)(-posd - cold));
+          }
+        for (int r2 = 0; r2 < 13; ++r2)
+          if (host[r2 * 17 + 16] != 0.0f) return CLWH_ERR_INTERNAL_OVERFLOW;
+        HIP_TRY(hipMalloc((void **)&ctx->bilateral_weights, sizeof host));
+        HIP_TRY(hipMemcpy(ctx->bilateral_weights, host, sizeof host, hipMemcpyHostToDevice));
+      }
+      HIP_TRY(launch_bilateral_filter((const int16_t *)src->dptr, (int)src->dims[0], (int)src->dims[1], (int)src->dims[2],
+                                      (int16_t *)dst->dptr, ctx->bilateral_weights, ctx->stream));
+      touch(dst);
       return CLWH_OK;
     }
 

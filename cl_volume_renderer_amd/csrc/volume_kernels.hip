@@ -1,6 +1,7 @@
 // volume_kernels.hip -- the volume pre-processing kernels next to the hot path:
 //   fetch_stats  opencl_kernels/reference_volume_figures.cl:10-26  min/max of value and of |gradient|
 //   apply_clip   opencl_kernels/reference_volume_clip.cl:4-15      copy of a sub-box
+//   bilateral_filter  opencl_kernels/volume_filter.cl:5-11         5x5x5 bilateral filter (LDS tile, host-built weight table)
 // Both are single HBM streams.  The reference issues four global atomics per voxel; here every wave
 // reduces with cross-lane operations, every block through LDS, and only one atomic per block and
 // statistic reaches memory.
@@ -64,6 +65,56 @@ __global__ __launch_bounds__(256) void k_apply_clip(const int16_t *__restrict__ 
   if ((unsigned)sx < (unsigned)SX && (unsigned)sy < (unsigned)SY && (unsigned)sz < (unsigned)SZ)
     v = src[((size_t)sz * (size_t)SY + (size_t)sy) * (size_t)SX + (size_t)sx];
   dst[((size_t)z * (size_t)DY + (size_t)y) * (size_t)DX + (size_t)x] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilateral_filter  opencl_kernels/volume_filter.cl:5-11 with bilateral_kernel utility_filter.cl:38-62:
+// 5x5x5 bilateral filter of the short volume (sigma_s 0.6, sigma_r 1).  The weight of a tap is
+// exp(-r2/(2*0.6^2) - d^2/2) with r2 the squared integer offset (13 values) and d the integer difference
+// to the centre voxel; it rounds to zero for |d| >= 16, so all weights the kernel can ever use are a
+// 13 x 17 table the host evaluates once in binary64 (`weights`, clwh_runtime.hip) -- no transcendental on
+// the device.  A block filters an 8x8x8 brick out of a 12^3 LDS tile (3.4 KB); the 125 taps are
+// accumulated in the reference's z, y, x order, un-contracted, so the two float sums round identically.
+// HBM traffic is one read and one write of the volume; the kernel is LDS/VALU bound (125 taps per voxel).
+constexpr int kBfR = 2, kBfB = 8, kBfT = kBfB + 2 * kBfR, kBfD = 17;
+__global__ __launch_bounds__(kBfB * kBfB * kBfB) void k_bilateral_filter(const int16_t *__restrict__ src, int X, int Y, int Z,
+                                                                          int16_t *__restrict__ dst,
+                                                                          const float *__restrict__ weights) {
+  __shared__ int16_t tile[kBfT][kBfT][kBfT];
+  __shared__ float wtab[13][kBfD];
+  const int tid = threadIdx.x;
+  const int bx = blockIdx.x * kBfB, by = blockIdx.y * kBfB, bz = blockIdx.z * kBfB;
+  for (int i = tid; i < 13 * kBfD; i += kBfB * kBfB * kBfB) (&wtab[0][0])[i] = weights[i];
+  for (int i = tid; i < kBfT * kBfT * kBfT; i += kBfB * kBfB * kBfB) {
+    const int lx = i % kBfT, ly = (i / kBfT) % kBfT, lz = i / (kBfT * kBfT);
+    const int gx = bx + lx - kBfR, gy = by + ly - kBfR, gz = bz + lz - kBfR;
+    int16_t v = 0;  // read_imagei outside the image: border 0
+    if ((unsigned)gx < (unsigned)X && (unsigned)gy < (unsigned)Y && (unsigned)gz < (unsigned)Z)
+      v = src[((size_t)gz * (size_t)Y + (size_t)gy) * (size_t)X + (size_t)gx];
+    tile[lz][ly][lx] = v;
+  }
+  __syncthreads();
+  const int lx = tid % kBfB, ly = (tid / kBfB) % kBfB, lz = tid / (kBfB * kBfB);
+  const int px = bx + lx, py = by + ly, pz = bz + lz;
+  if (px >= X || py >= Y || pz >= Z) return;
+  const int mid = tile[lz + kBfR][ly + kBfR][lx + kBfR];
+  float out_colour = 0.0f, wp = 0.0f;
+#pragma unroll
+  for (int z = -kBfR; z <= kBfR; ++z)
+#pragma unroll
+    for (int y = -kBfR; y <= kBfR; ++y)
+#pragma unroll
+      for (int x = -kBfR; x <= kBfR; ++x) {
+        const int local = tile[lz + kBfR + z][ly + kBfR + y][lx + kBfR + x];
+        const int d = min(abs(mid - local), kBfD - 1);
+        const float w = wtab[x * x + y * y + z * z][d];
+        wp = wp + w;
+        out_colour = out_colour + (float)local * w;
+      }
+  const float q = out_colour / wp;  // wp >= 1: the centre tap weighs exp(0)
+  int32_t r = f2i(q);
+  r = max(-32768, min(32767, r));
+  dst[((size_t)pz * (size_t)Y + (size_t)py) * (size_t)X + (size_t)px] = (int16_t)r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -151,6 +202,12 @@ __global__ __launch_bounds__(256) void k_tf_flush_color_frame(uint32_t *color_fr
 }
 
 static unsigned row_block(int X) { return X <= 64 ? 64u : (X <= 128 ? 128u : 256u); }
+
+hipError_t launch_bilateral_filter(const int16_t *src, int X, int Y, int Z, int16_t *dst, const float *weights, hipStream_t s) {
+  const dim3 grid(((unsigned)X + kBfB - 1u) / kBfB, ((unsigned)Y + kBfB - 1u) / kBfB, ((unsigned)Z + kBfB - 1u) / kBfB);
+  hipLaunchKernelGGL(k_bilateral_filter, grid, dim3(kBfB * kBfB * kBfB), 0, s, src, X, Y, Z, dst, weights);
+  return hipGetLastError();
+}
 
 hipError_t launch_fetch_stats(const int16_t *vol, int X, int Y, int Z, int32_t *stats, hipStream_t s) {
   const unsigned b = row_block(X);

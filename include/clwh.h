@@ -96,8 +96,8 @@ int clwh_mem_mark_dirty(clwh_mem *mem);
  * Known pairs: ("ray_marching.cl","render"), ("signed_distance_field.cl","create_base_image"),
  * ("signed_distance_field.cl","create_signed_distance_field"), ("buffer_reset.cl","buffer_reset"),
  * ("empty.cl","empty"), and next to the hot path ("reference_volume_figures.cl","fetch_stats"),
- * ("reference_volume_clip.cl","apply_clip"), ("histogram.cl","tf_sort_values"),
- * ("histogram.cl","tf_flush_color_frame").
+ * ("reference_volume_clip.cl","apply_clip"), ("volume_filter.cl","bilateral_filter"),
+ * ("histogram.cl","tf_sort_values"), ("histogram.cl","tf_flush_color_frame").
  */
 int clwh_kernel_get(clwh_ctx *ctx, const char *file, const char *entry, const char *prepend,
                     clwh_kernel **out);

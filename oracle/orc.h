@@ -108,6 +108,9 @@ int orc_sdf_build(const int16_t *volume, int32_t X, int32_t Y, int32_t Z, const 
                   int8_t *sdf_out, int32_t *n_launches, int32_t *layer_counts);
 
 /* opencl_kernels/buffer_reset.cl:3-13 */
+/* volume_filter.cl:5-11 + utility_filter.cl:38-62: 5x5x5 bilateral filter of a short volume (orc_filter.c) */
+void orc_bilateral_filter(const int16_t *volume, int32_t X, int32_t Y, int32_t Z, int16_t *out);
+
 void orc_buffer_reset(uint16_t *cache, int32_t X, int32_t Y, int32_t Z);
 
 /* app/common.hpp:5-12 Position3D(alpha, beta, 0, {1,0,0}) */

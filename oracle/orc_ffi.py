@@ -64,7 +64,7 @@ def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it."""
     if force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-        for f in ("orc_render.c", "orc_sdf.c", "orc.h", "Makefile")
+        for f in ("orc_render.c", "orc_sdf.c", "orc_filter.c", "orc.h", "Makefile")
     ):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
@@ -90,6 +90,8 @@ def lib():
                                     C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]
         L.orc_buffer_reset.restype = None
         L.orc_buffer_reset.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        L.orc_bilateral_filter.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.orc_bilateral_filter.restype = None
         L.orc_camera_direction.restype = None
         L.orc_camera_direction.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_float)]
         L.orc_hash.restype = C.c_uint32
@@ -209,6 +211,15 @@ def parse_tf(source: str) -> Tf:
 
 def cache_len(X, Y, Z) -> int:
     return int(lib().orc_cache_len(X, Y, Z))
+
+
+def bilateral_filter(volume: np.ndarray) -> np.ndarray:
+    """volume_filter.cl:5-11 over a (Z, Y, X) int16 array"""
+    v = np.ascontiguousarray(volume, dtype=np.int16)
+    out = np.empty_like(v)
+    Z, Y, X = v.shape
+    lib().orc_bilateral_filter(v.ctypes.data, X, Y, Z, out.ctypes.data)
+    return out
 
 
 def sdf_build(volume: np.ndarray, tf: Tf):

@@ -84,7 +84,7 @@ def test_degenerate_volumes(gpu_ctx, orc):
 
 def test_unknown_kernel_and_bad_ndrange_are_reported(gpu_ctx):
     with pytest.raises(ffi.ClwhError) as e:
-        gpu_ctx.kernel("volume_filter.cl", "bilateral_filter")
+        gpu_ctx.kernel("2d_image_filter.cl", "bilateral_filter")
     assert e.value.status == 5
     k = gpu_ctx.kernel("empty.cl", "empty")
     with pytest.raises(ffi.ClwhError) as e:

@@ -28,6 +28,55 @@ def test_fetch_stats(gpu_ctx, dims):
     k.release()
 
 
+def _bilateral(gpu_ctx, vol):
+    Z, Y, X = vol.shape
+    v = gpu_ctx.image_from(vol)
+    dst = gpu_ctx.image([X, Y, Z], 1, np.int16, (Z, Y, X))
+    ev = lambda g: (g + 7) // 8 * 8  # noqa: E731  get_volume_size_evenness(8), app/reference_volume.cpp:76
+    k = gpu_ctx.kernel("volume_filter.cl", "bilateral_filter")
+    k.launch([ev(X), ev(Y), ev(Z)], [4, 4, 4], v, dst)
+    got = dst.pull()
+    for m in (v, dst):
+        m.release()
+    k.release()
+    return got
+
+
+@pytest.mark.parametrize("dims", [(32, 32, 32), (37, 21, 13), (9, 5, 3), (2, 2, 2), (2, 1, 1), (70, 8, 8)])
+def test_bilateral_filter_noise(gpu_ctx, orc, dims):
+    """volume_filter.cl:5-11 on noise with small differences, so that most of the 125 range weights are non-zero
+    (incl. denormal ones), ragged sizes, and the zero border"""
+    rng = np.random.default_rng(sum(dims))
+    X, Y, Z = dims
+    vol = (rng.integers(-6, 7, (Z, Y, X)) + rng.integers(-3, 4, (Z, 1, 1)) * 5).astype(np.int16)
+    assert np.array_equal(_bilateral(gpu_ctx, vol), orc.bilateral_filter(vol))
+
+
+def test_bilateral_filter_phantom_and_extremes(gpu_ctx, orc):
+    vol = scene.phantom(72, dims=(72, 64, 56))
+    got = _bilateral(gpu_ctx, vol)
+    assert np.array_equal(got, orc.bilateral_filter(vol))
+    assert not np.array_equal(got, vol)
+    ext = np.full((12, 12, 12), 32767, np.int16)
+    ext[::2] = -32768
+    ext[5, 5, 5] = 17
+    assert np.array_equal(_bilateral(gpu_ctx, ext), orc.bilateral_filter(ext))
+
+
+def test_bilateral_filter_rejects_in_place_and_mismatched_images(gpu_ctx):
+    from cl_volume_renderer_amd import ffi
+
+    a = gpu_ctx.image([8, 8, 8], 1, np.int16, (8, 8, 8))
+    b = gpu_ctx.image([8, 8, 4], 1, np.int16, (4, 8, 8))
+    k = gpu_ctx.kernel("volume_filter.cl", "bilateral_filter")
+    for src, dst in ((a, a), (a, b)):
+        with pytest.raises(ffi.ClwhError):
+            k.launch([8, 8, 8], [4, 4, 4], src, dst)
+    for m in (a, b):
+        m.release()
+    k.release()
+
+
 def test_apply_clip(gpu_ctx):
     vol = scene.phantom(48, dims=(48, 40, 36))
     v = gpu_ctx.image_from(vol)

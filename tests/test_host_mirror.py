@@ -33,6 +33,7 @@ def _host():
     L.clvr_host_camera_direction.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float)]
     L.clvr_host_volume_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     L.clvr_host_set_clipping.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    L.clvr_host_filter.argtypes = [C.c_void_p]
     L.clvr_host_render_tf.restype = C.c_void_p
     L.clvr_host_render_tf.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
     return L
@@ -57,9 +58,9 @@ def test_renderer_frame_emitter_sequence_matches_oracle(orc):
     vol = scene.phantom(n)
     env = scene.env_map(256, 128)
     tf = scene.tf_default_source()
-    pos = np.array([-20.0, 40.0, -20.0], np.float32)
-    look = np.array([0.8, 6.0], np.float32)
-    W, H = 160, 96            # launch size (state.width/height); the frame image stays 2048x1024
+    pos = np.array([-110.0, 150.0, -110.0], np.float32)
+    look = np.array([0.1, 6.6], np.float32)
+    W, H = 512, 256           # launch size (state.width/height); the frame image stays 2048x1024
 
     libc = C.CDLL("libc.so.6")
     libc.srand(1)             # the state a fresh process has (app/renderer.cpp:142 never calls srand)
@@ -91,6 +92,7 @@ def test_renderer_frame_emitter_sequence_matches_oracle(orc):
     cache = np.empty(L.clvr_host_cache_len(h), np.uint16)
     L.clvr_host_pull_cache(h, cache.ctypes.data)
     assert np.array_equal(cache, o.cache)
+    assert 0 < cache.reshape(-1, 4)[:, 3].max() < 256  # below the token cap the cache is order-independent
     o.resolve(pos, d)
     frame = np.ctypeslib.as_array(C.cast(frame_ptr, C.POINTER(C.c_uint8)), shape=(1024, 2048, 4))
     assert np.array_equal(frame[:H, :W], o.frame[:H, :W])
@@ -126,9 +128,9 @@ def test_reference_volume_stats_and_clipping(orc):
 
     libc = C.CDLL("libc.so.6")
     libc.srand(1)
-    pos = np.array([-16.0, 30.0, -14.0], np.float32)
-    look = np.array([0.8, 6.0], np.float32)
-    W, H = 96, 64
+    pos = np.array([-110.0, 150.0, -110.0], np.float32)
+    look = np.array([0.1, 6.6], np.float32)
+    W, H = 512, 256
     changed = C.c_int(0)
     L.clvr_host_render_frame(h, pos.ctypes.data_as(C.POINTER(C.c_float)), look.ctypes.data_as(C.POINTER(C.c_float)),
                              W, H, 1, C.byref(changed))
@@ -137,6 +139,46 @@ def test_reference_volume_stats_and_clipping(orc):
     cache = np.empty(L.clvr_host_cache_len(h), np.uint16)
     L.clvr_host_pull_cache(h, cache.ctypes.data)
     assert np.array_equal(cache, o.cache)
+    assert 0 < cache.reshape(-1, 4)[:, 3].max() < 256  # below the token cap the cache is order-independent
+    L.clvr_host_destroy(h)
+
+
+@pytest.mark.gpu
+def test_reference_volume_filter_replaces_the_device_volume(orc):
+    """reference_volume::filter (app/reference_volume.cpp:70-80): after "Apply Filter" + flush, SDF and render
+    work on the bilaterally filtered volume"""
+    L = _host()
+    n = 48
+    vol = scene.phantom(n)
+    env = scene.env_map(128, 64)
+    # a threshold inside the phantom's noise band, so that filtering changes which voxels are surface
+    tf = scene.tf_default_source().replace("value >= 500", "value >= -1000")
+    assert "value >= -1000" in tf
+    h = L.clvr_host_create()
+    L.clvr_host_load(h, vol.ctypes.data, n, n, n, env.ctypes.data, env.shape[1], env.shape[0])
+    L.clvr_host_filter(h)
+    L.clvr_host_flush(h, tf.encode())
+    filtered = orc.bilateral_filter(vol)
+    assert not np.array_equal(filtered, vol)
+    sdf = np.empty(L.clvr_host_sdf_len(h), np.int8)
+    L.clvr_host_pull_sdf(h, sdf.ctypes.data)
+    want_sdf, _, _ = orc.sdf_build(filtered, orc.parse_tf(tf))
+    assert np.array_equal(sdf.reshape(vol.shape), want_sdf)
+    assert not np.array_equal(want_sdf, orc.sdf_build(vol, orc.parse_tf(tf))[0])
+    libc = C.CDLL("libc.so.6")
+    libc.srand(1)
+    pos = np.array([-110.0, 150.0, -110.0], np.float32)
+    look = np.array([0.1, 6.6], np.float32)
+    W, H = 512, 256
+    changed = C.c_int(0)
+    L.clvr_host_render_frame(h, pos.ctypes.data_as(C.POINTER(C.c_float)), look.ctypes.data_as(C.POINTER(C.c_float)),
+                             W, H, 1, C.byref(changed))
+    o = orc.Scene(filtered, want_sdf, env, orc.parse_tf(tf), (2048, 1024), (W, H))
+    o.render(pos, scene.camera_direction(look[0], look[1]), scene.glibc_rand(1)[0])
+    cache = np.empty(L.clvr_host_cache_len(h), np.uint16)
+    L.clvr_host_pull_cache(h, cache.ctypes.data)
+    assert np.array_equal(cache, o.cache)
+    assert 0 < cache.reshape(-1, 4)[:, 3].max() < 256  # below the token cap the cache is order-independent
     L.clvr_host_destroy(h)
 
 
@@ -252,14 +294,14 @@ def test_headless_application_renders_the_oracles_frame(orc, tmp_path):
     import json
     import subprocess
 
-    n = 48
+    n = 192  # large enough that the start-up view stays below the 256-token cap (order-independent cache)
     vol = scene.phantom(n)
     scene.write_nrrd(str(tmp_path / "v.nrrd"), vol, use_gzip=True)
     rng = np.random.default_rng(5)
     rgbe = scene.float_to_rgbe((rng.random((64, 128, 3), dtype=np.float32) * 1.5).astype(np.float32))
     scene.write_hdr(str(tmp_path / "e.hdr"), rgbe)
     env = scene.rgbe_to_ldr(rgbe)
-    W, H, frames = 160, 96, 3
+    W, H, frames = 1024, 512, 2
     exe = os.path.join(ROOT, "cl_volume_renderer_amd", "clvr_headless")
     out = subprocess.run([exe, str(tmp_path / "v.nrrd"), str(tmp_path / "e.hdr"), str(frames), str(W), str(H)],
                          capture_output=True, text=True, timeout=120)
@@ -274,6 +316,7 @@ def test_headless_application_renders_the_oracles_frame(orc, tmp_path):
     d = scene.camera_direction(0.9, 6.183)
     for seed in scene.glibc_rand(frames):
         o.render(pos, d, seed)
+    assert 0 < o.cache.reshape(-1, 4)[:, 3].max() < 256 and (o.hit_index >= 0).sum() > 10000
     o.resolve(pos, d)
     h = 1469598103934665603
     for b in o.frame[:H, :W].tobytes():
