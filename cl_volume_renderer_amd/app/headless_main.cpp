@@ -46,6 +46,10 @@ int main(int argc, char const *argv[]) {
   const double scale = rv.get_volume_size()[0] / 512.0;  // the default camera is placed for a 512^3 volume
   state.position = Position3D(-200 * scale, 200 * scale, -200 * scale);
   const unsigned char *frame = nullptr;
+  // renderer::render_frame seeds every pass from std::rand() and the application never calls srand
+  // (app/renderer.cpp:142).  The ROCm runtime draws from rand() while it initialises, so the sequence is put
+  // back to the never-seeded state here to make the frames reproducible (1804289383, 846930886, ...).
+  std::srand(1);
   const auto t0 = std::chrono::steady_clock::now();
   for (int f = 0; f < frames; ++f) {
     bool changed = false;

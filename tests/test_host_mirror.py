@@ -62,11 +62,13 @@ def test_renderer_frame_emitter_sequence_matches_oracle(orc):
     look = np.array([0.1, 6.6], np.float32)
     W, H = 512, 256           # launch size (state.width/height); the frame image stays 2048x1024
 
-    libc = C.CDLL("libc.so.6")
-    libc.srand(1)             # the state a fresh process has (app/renderer.cpp:142 never calls srand)
     h = L.clvr_host_create()
     L.clvr_host_load(h, vol.ctypes.data, n, n, n, env.ctypes.data, env.shape[1], env.shape[0])
     L.clvr_host_flush(h, tf.encode())
+    # the state a fresh process has (app/renderer.cpp:142 never calls srand).  Set AFTER the context exists: the
+    # ROCm runtime draws from rand() while it initialises, which would shift the renderer's seed sequence.
+    libc = C.CDLL("libc.so.6")
+    libc.srand(1)
 
     sdf = np.empty(L.clvr_host_sdf_len(h), np.int8)
     L.clvr_host_pull_sdf(h, sdf.ctypes.data)
