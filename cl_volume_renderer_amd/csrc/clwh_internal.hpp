@@ -78,6 +78,7 @@ struct RenderArgs {
   int32_t seeds[CLWH_MAX_SEEDS];
   // scheduling knobs of k_bounce (defaults in clwh_runtime.hip; CLWH_TUNE_* override for experiments)
   int32_t step_min_lanes;    // keep stepping while at least this many lanes march
+  int32_t refill_min_lanes;  // idle lanes fetch new items once this many are idle (64: only an empty wave refills)
   uint32_t bounce_max_blocks;  // persistent grid size (256-thread blocks)
   int32_t unit_group;          // chunks per queue group (see k_bounce refill)
   int32_t unit_queues;         // number of unit queues (1..8)
@@ -186,9 +187,10 @@ struct clwh_ctx {
   bool fixup_overflow_pending = false;
   // measured on MI355X (profiles/r01_tune_*.txt): a wave that runs its 64 samples to completion with
   // steps and events in separate wave-wide phases beats mid-flight refills (12.5 vs 7.6 Gsamples/s)
-  int32_t tune_step_min_lanes = 1;
+  int32_t tune_step_min_lanes = 16;
+  int32_t tune_refill_min_lanes = 16;
   int32_t tune_literal_gradient = 0;
-  int32_t tune_unit_group = 16, tune_unit_affinity = 0, tune_unit_queues = 8;
+  int32_t tune_unit_group = 8, tune_unit_affinity = 0, tune_unit_queues = 8;
   uint32_t tune_bounce_max_blocks = 2048;
   bool primary_valid = false;
   uint32_t primary_n_hits = 0;

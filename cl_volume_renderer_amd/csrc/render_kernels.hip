@@ -259,72 +259,86 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
   bool exhausted = false;  // wave-uniform: the queue has no more items
 
   for (;;) {
-    // ---- refill: an empty wave pulls one unit = (chunk of 64 consecutive hits, seed) -----------------
-    // Units are dealt to eight queues by chunk number; a wave serves the queue of the XCD it runs on
-    // first (so the 16 seeds of one chunk -- a thousand rays leaving the same few voxels -- meet in ONE
-    // L2) and steals from the other queues when its own is dry.  Placement only affects speed.
-    if (!exhausted && __ballot(st != ST_IDLE) == 0ull) {
-      uint32_t unit = 0xFFFFFFFFu;
+    // ---- refill: idle lanes pull consecutive items of the unit queues ---------------------------------
+    // An item is (hit, seed); 64 consecutive items of a queue are one unit = (chunk of 64 consecutive hits,
+    // seed).  Units are dealt to eight queues by chunk number; a wave serves the queue of the XCD it runs on
+    // first (so the seeds of one chunk -- thousands of rays leaving the same few voxels -- meet in ONE L2)
+    // and steals from the other queues when its own is dry.  As soon as `refill_min_lanes` lanes are idle
+    // they take the next items in queue order (one atomic per refill), so a wave does not drain down to its
+    // slowest sample before it gets new work.  Placement only affects speed.
+    const unsigned long long idle_mask = __ballot(st == ST_IDLE);
+    const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+    if (!exhausted && n_idle >= (uint32_t)a.refill_min_lanes) {
+      const uint32_t NQ = (uint32_t)a.unit_queues, S = (uint32_t)a.n_seeds, G = (uint32_t)a.unit_group;
+      uint32_t base = 0u, count = 0u, q_sel = 0u;
       if (lane == 0u) {
-        const unsigned NQ = (unsigned)a.unit_queues;
-        for (unsigned tries = 0; tries < NQ && unit == 0xFFFFFFFFu; ++tries) {
-          const unsigned q = (home_queue + tries) % NQ;
+        for (uint32_t tries = 0; tries < NQ && count == 0u; ++tries) {
+          const uint32_t q = (home_queue + tries) % NQ;
           const uint32_t chunks_q = (n_chunks + NQ - 1u - q) / NQ;  // chunks c with c % NQ == q
           if (chunks_q == 0u || ((queue_dry >> q) & 1u)) continue;
+          const uint32_t total = chunks_q * S * 64u;
           // every head sits on its own 128-byte line: same-address atomics serialise at one L2 channel
-          const uint32_t p = atomicAdd(&a.counters[32u * (q + 1u)], 1u);
-          if (p >= chunks_q * (uint32_t)a.n_seeds) queue_dry |= 1u << q;  // remembered: never asked again
-          if (p < chunks_q * (uint32_t)a.n_seeds) {
-            // queue order: groups of `unit_group` chunks, inside a group seed-major -- the 16 seeds of a chunk
-            // are `unit_group` units apart (their accumulation atomics do not collide) yet close enough to
-            // find each other's voxels still in L2
-            const uint32_t S = (uint32_t)a.n_seeds, G = (uint32_t)a.unit_group;
-            const uint32_t g = p / (G * S), r = p - g * (G * S);
-            const uint32_t in_group = min(G, chunks_q - g * G);  // the last group may be short
-            const uint32_t sd_i = r / in_group, ch = g * G + (r - sd_i * in_group);
-            unit = ((q + NQ * ch) << 6) | sd_i;
+          const uint32_t p = atomicAdd(&a.counters[32u * (q + 1u)], n_idle);
+          if (p + n_idle >= total) queue_dry |= 1u << q;  // remembered: never asked again
+          if (p < total) {
+            base = p;
+            count = min(n_idle, total - p);
+            q_sel = q;
           }
         }
       }
-      unit = __shfl(unit, 0);
-      if (unit == 0xFFFFFFFFu) {
-        exhausted = true;
-      } else {
-        const uint32_t h = (unit >> 6) * 64u + lane, s = unit & 63u;
-        if (h < a.n_hits) {
-          fix = -1;
-          npend = 0;
-          const uint4 *src = reinterpret_cast<const uint4 *>(&a.hits[h]);
-          const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-          hit_origin = f3{__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
-          hit_direction = f3{__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
-          normal = f3{__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)};
-          color = q2.y;
-          entry = (int64_t)(((uint64_t)q2.w << 32) | (uint64_t)q2.z);
-          gx = q3.x & 0xFFFFu;
-          gy = q3.x >> 16;
-          hit = h;
-          seed = a.seeds[s];
-          bool granted = true;
-          if (MODE == CLWH_ACCUM_VOXEL_CACHE) granted = entry >= 0 && cache_take_token(a.cache, entry, 256u);
-          if (granted) {
-            r_energy = (float)(color & 255u) / 255.0f;
-            g_energy = (float)((color >> 8) & 255u) / 255.0f;
-            b_energy = (float)((color >> 16) & 255u) / 255.0f;
-            bv_r = bv_g = bv_b = 0u;
-            o = 1;
-            st = ST_EVENT;
-            ev = EV_START;
-          } else if (a.contrib_out) {
-            uint32_t *q = a.contrib_out + ((size_t)gy * (size_t)a.launch_w + gx) * 4;
-            q[0] = 0u; q[1] = 0u; q[2] = 0u; q[3] = 0u;
+      base = __shfl(base, 0);
+      count = __shfl(count, 0);
+      q_sel = __shfl(q_sel, 0);
+      if (count == 0u) {
+        exhausted = true;  // every queue is dry
+      } else if (st == ST_IDLE) {
+        const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+        if (rank < count) {
+          const uint32_t item = base + rank, p = item >> 6;
+          // queue order: groups of `unit_group` chunks, inside a group seed-major -- the seeds of a chunk are
+          // `unit_group` units apart (their accumulation atomics do not collide) yet close enough to find
+          // each other's voxels still in L2
+          const uint32_t chunks_q = (n_chunks + NQ - 1u - q_sel) / NQ;
+          const uint32_t g = p / (G * S), r = p - g * (G * S);
+          const uint32_t in_group = min(G, chunks_q - g * G);  // the last group may be short
+          const uint32_t s = r / in_group, ch = g * G + (r - s * in_group);
+          const uint32_t h = (q_sel + NQ * ch) * 64u + (item & 63u);
+          if (h < a.n_hits) {
+            fix = -1;
+            npend = 0;
+            const uint4 *src = reinterpret_cast<const uint4 *>(&a.hits[h]);
+            const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+            hit_origin = f3{__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
+            hit_direction = f3{__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
+            normal = f3{__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)};
+            color = q2.y;
+            entry = (int64_t)(((uint64_t)q2.w << 32) | (uint64_t)q2.z);
+            gx = q3.x & 0xFFFFu;
+            gy = q3.x >> 16;
+            hit = h;
+            seed = a.seeds[s];
+            bool granted = true;
+            if (MODE == CLWH_ACCUM_VOXEL_CACHE) granted = entry >= 0 && cache_take_token(a.cache, entry, 256u);
+            if (granted) {
+              r_energy = (float)(color & 255u) / 255.0f;
+              g_energy = (float)((color >> 8) & 255u) / 255.0f;
+              b_energy = (float)((color >> 16) & 255u) / 255.0f;
+              bv_r = bv_g = bv_b = 0u;
+              o = 1;
+              st = ST_EVENT;
+              ev = EV_START;
+            } else if (a.contrib_out) {
+              uint32_t *q = a.contrib_out + ((size_t)gy * (size_t)a.launch_w + gx) * 4;
+              q[0] = 0u; q[1] = 0u; q[2] = 0u; q[3] = 0u;
+            }
           }
         }
       }
     }
     if (__ballot(st != ST_IDLE) == 0ull) {
       if (exhausted) break;  // nothing in flight and nothing left to fetch
-      continue;              // every sample of the unit was refused its token: fetch the next unit
+      continue;              // every fetched sample was refused its token (or was padding): fetch again
     }
 
     // ---- step phase: MARCH lanes step until fewer than kStepPhaseMinLanes are still marching -----
