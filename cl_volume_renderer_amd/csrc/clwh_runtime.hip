@@ -671,6 +671,17 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     HIP_TRY(hipEventRecord(ev_b, ctx->stream));
   }
   HIP_TRY(launch_bounce(a, ctx->stream));
+#ifdef CLVR_BOUNCE_STATS  // experiment builds only (CLVR_EXTRA_HIPCC_FLAGS=-DCLVR_BOUNCE_STATS): scheduling statistics of the launch
+  {
+    uint32_t h[18];
+    HIP_TRY(hipMemcpyAsync(h, ctx->render_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::fprintf(stderr, "[bounce stats] items=%llu step_iters=%u avg_march_lanes=%.2f event_phases=%u avg_event_lanes=%.2f "
+                 "refills=%u avg_refill=%.2f events start/exit/hit/none=%u/%u/%u/%u\n",
+                 (unsigned long long)a.n_hits * (unsigned long long)a.n_seeds, h[8], h[8] ? (double)h[9] / h[8] : 0.0, h[10],
+                 h[10] ? (double)h[11] / h[10] : 0.0, h[12], h[12] ? (double)h[13] / h[12] : 0.0, h[14], h[15], h[16], h[17]);
+  }
+#endif
   HIP_TRY(launch_env_fixup(a, ctx->stream));
   HIP_TRY(launch_commit(a, ctx->stream));
   ctx->fixup_overflow_pending = true;

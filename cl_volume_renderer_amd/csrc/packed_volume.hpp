@@ -29,13 +29,54 @@ struct VolumePacked {
   int X, Y, Z;
   int NBX, NBY;  // bricks per row / per slice
 
+  // offset of a voxel inside its 8x8x8 brick
+  __host__ __device__ static inline unsigned inner_index(unsigned ux, unsigned uy, unsigned uz) {
+#ifdef CLVR_BRICK_SLAB  // experiment: plain z-y-x order, a 64-byte line of step bytes is an 8x8x1 slab (5 ALU ops instead of 15)
+    return ((uz & 7u) << 6) | ((uy & 7u) << 3) | (ux & 7u);
+#else
+    return ((uz & 4u) << 6) | ((uy & 4u) << 5) | ((ux & 4u) << 4) | ((uz & 3u) << 4) | ((uy & 3u) << 2) | (ux & 3u);
+#endif
+  }
+  // inverse of inner_index
+  __host__ __device__ static inline void inner_coords(unsigned inner, unsigned &x, unsigned &y, unsigned &z) {
+#ifdef CLVR_BRICK_SLAB
+    x = inner & 7u; y = (inner >> 3) & 7u; z = inner >> 6;
+#else
+    x = (inner & 3u) | ((inner >> 4) & 4u); y = ((inner >> 2) & 3u) | ((inner >> 5) & 4u); z = ((inner >> 4) & 3u) | ((inner >> 6) & 4u);
+#endif
+  }
+
+  // The record index is separable: index(x, y, z) = part_x(x) + part_y(y) + part_z(z) -- the brick number is a sum
+  // of per-axis terms and the in-brick bit fields of the three axes are disjoint.  The 6-tap normal needs nine
+  // part evaluations instead of six full index computations.  SMALL (fewer than 2^23 bricks): parts are 32-bit and
+  // use full-rate 24-bit multiply-adds (the compiler turns __umul24 back into quarter-rate 32/64-bit multiplies).
+  template <bool SMALL> struct Index { using type = size_t; };
+  __device__ __forceinline__ static unsigned mul24_uniform(unsigned v, int uniform) {
+    unsigned r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(v), "s"(uniform));
+    return r;
+  }
+  template <bool SMALL>
+  __device__ __forceinline__ typename Index<SMALL>::type part_x(unsigned u) const {
+    return ((typename Index<SMALL>::type)(u >> 3) << 9) | inner_index(u, 0u, 0u);
+  }
+  template <bool SMALL>
+  __device__ __forceinline__ typename Index<SMALL>::type part_y(unsigned u) const {
+    const unsigned b = SMALL ? mul24_uniform(u >> 3, NBX) : (u >> 3) * (unsigned)NBX;
+    return ((typename Index<SMALL>::type)b << 9) | inner_index(0u, u, 0u);
+  }
+  template <bool SMALL>
+  __device__ __forceinline__ typename Index<SMALL>::type part_z(unsigned u) const {
+    const unsigned b = SMALL ? mul24_uniform(u >> 3, NBX * NBY) : (u >> 3) * (unsigned)(NBX * NBY);
+    return ((typename Index<SMALL>::type)b << 9) | inner_index(0u, 0u, u);
+  }
+
   // coordinates are non-negative and in range; the brick number fits 32 bits for every volume that
   // fits the GPU (2048^3 has 2^24 bricks), so only the final scale by 512 records is 64-bit
   __host__ __device__ static inline size_t record_index(int x, int y, int z, int nbx, int nby) {
     const unsigned ux = (unsigned)x, uy = (unsigned)y, uz = (unsigned)z;
     const unsigned brick = ((uz >> 3) * (unsigned)nby + (uy >> 3)) * (unsigned)nbx + (ux >> 3);
-    const unsigned inner = ((uz & 4u) << 6) | ((uy & 4u) << 5) | ((ux & 4u) << 4) | ((uz & 3u) << 4) | ((uy & 3u) << 2) | (ux & 3u);
-    return ((size_t)brick << 9) + inner;
+    return ((size_t)brick << 9) + inner_index(ux, uy, uz);
   }
 
   // int coordinates (read_imagei(img, int4)): out of range -> border record 0
@@ -52,9 +93,21 @@ struct VolumePacked {
 
   // the march's per-step byte (gradient-free transfer functions): one 64-byte line holds a whole 4x4x4
   // sub-brick, the whole 512^3 array is 128 MiB and stays resident in the 256 MiB Infinity Cache
+  template <bool SMALL = false>
   __device__ __forceinline__ unsigned step_i(int x, int y, int z) const {
     if ((unsigned)x >= (unsigned)X || (unsigned)y >= (unsigned)Y || (unsigned)z >= (unsigned)Z) return 0u;
-    return stepb[record_index(x, y, z, NBX, NBY)];
+    return stepb[part_x<SMALL>((unsigned)x) + part_y<SMALL>((unsigned)y) + part_z<SMALL>((unsigned)z)];
+  }
+  // The march's fetch after `!exited_volume(pos)`: every coordinate is then >= 0 (or -0.0), <= its dimension, or
+  // NaN.  trunc == floor for such values, so only `coordinate < dimension` remains to be tested (false for NaN
+  // and for coordinate == dimension, which both read the border), and the in-brick offset is formed in 32 bits
+  // so that the load can use scalar-base + 32-bit-offset addressing.  SMALL: the volume has fewer than 2^23
+  // bricks, every step byte has a 32-bit offset and the brick number is formed with 24-bit multiplies.
+  template <bool SMALL>
+  __device__ __forceinline__ unsigned step_marched(float fx, float fy, float fz) const {
+    if (!(fx < (float)X && fy < (float)Y && fz < (float)Z)) return 0u;
+    const unsigned ux = (unsigned)(int)fx, uy = (unsigned)(int)fy, uz = (unsigned)(int)fz;
+    return stepb[part_x<SMALL>(ux) + part_y<SMALL>(uy) + part_z<SMALL>(uz)];
   }
   __device__ __forceinline__ unsigned step_f(float fx, float fy, float fz) const {
     const float gx = floorf(fx), gy = floorf(fy), gz = floorf(fz);
@@ -80,5 +133,6 @@ struct VolumePacked {
   __device__ __forceinline__ int value_at(float fx, float fy, float fz) const { return value_of(fetch_f(fx, fy, fz)); }
   __device__ __forceinline__ int sdf_at(int x, int y, int z) const { return sdf_of(fetch_i(x, y, z)); }
 };
+template <> struct VolumePacked::Index<true> { using type = uint32_t; };
 
 }  // namespace clvr

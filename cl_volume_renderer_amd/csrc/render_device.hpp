@@ -41,17 +41,39 @@ __device__ __forceinline__ bool tf_eval(const TfDev &tf, int value_in, int gradi
 // ------------------------------------------------------------------------------------------------
 // utility_filter.cl:2-35: central differences v(p+e_k) - v(p-e_k), no 1/2 factor, border texel = 0;
 // the six taps read packed records, all loads issued before any is consumed
+// Per axis the taps use three texel coordinates -- floor(c - 1), floor(c), floor(c + 1) (the reference adds +-1 in
+// float, which is not always floor(c) +- 1) -- and the record index is separable (packed_volume.hpp), so nine
+// per-axis parts and nine range flags serve all six taps.  An out-of-range coordinate contributes part 0 (a valid
+// address) and masks the tap to the border value 0.
+template <bool SMALL = false>
 __device__ __forceinline__ f3 gradient_nn(const VolumePacked &v, f3 p) {
-  const uint32_t xp = v.fetch_f_masked(p.x + 1.0f, p.y + 0.0f, p.z + 0.0f);
-  const uint32_t xm = v.fetch_f_masked(p.x - 1.0f, p.y - 0.0f, p.z - 0.0f);
-  const uint32_t yp = v.fetch_f_masked(p.x + 0.0f, p.y + 1.0f, p.z + 0.0f);
-  const uint32_t ym = v.fetch_f_masked(p.x - 0.0f, p.y - 1.0f, p.z - 0.0f);
-  const uint32_t zp = v.fetch_f_masked(p.x + 0.0f, p.y + 0.0f, p.z + 1.0f);
-  const uint32_t zm = v.fetch_f_masked(p.x - 0.0f, p.y - 0.0f, p.z - 1.0f);
-  const int dx = VolumePacked::value_of(xp) - VolumePacked::value_of(xm);
-  const int dy = VolumePacked::value_of(yp) - VolumePacked::value_of(ym);
-  const int dz = VolumePacked::value_of(zp) - VolumePacked::value_of(zm);
-  return f3{(float)dx, (float)dy, (float)dz};
+  using idx_t = typename VolumePacked::Index<SMALL>::type;
+  const float gx0 = floorf(p.x), gxp = floorf(p.x + 1.0f), gxm = floorf(p.x - 1.0f);
+  const float gy0 = floorf(p.y), gyp = floorf(p.y + 1.0f), gym = floorf(p.y - 1.0f);
+  const float gz0 = floorf(p.z), gzp = floorf(p.z + 1.0f), gzm = floorf(p.z - 1.0f);
+  const float fX = (float)v.X, fY = (float)v.Y, fZ = (float)v.Z;
+  const bool ox0 = gx0 >= 0.0f && gx0 < fX, oxp = gxp >= 0.0f && gxp < fX, oxm = gxm >= 0.0f && gxm < fX;  // false for NaN
+  const bool oy0 = gy0 >= 0.0f && gy0 < fY, oyp = gyp >= 0.0f && gyp < fY, oym = gym >= 0.0f && gym < fY;
+  const bool oz0 = gz0 >= 0.0f && gz0 < fZ, ozp = gzp >= 0.0f && gzp < fZ, ozm = gzm >= 0.0f && gzm < fZ;
+  const idx_t x0 = v.template part_x<SMALL>((unsigned)(int)(ox0 ? gx0 : 0.0f));
+  const idx_t xp = v.template part_x<SMALL>((unsigned)(int)(oxp ? gxp : 0.0f));
+  const idx_t xm = v.template part_x<SMALL>((unsigned)(int)(oxm ? gxm : 0.0f));
+  const idx_t y0 = v.template part_y<SMALL>((unsigned)(int)(oy0 ? gy0 : 0.0f));
+  const idx_t yp = v.template part_y<SMALL>((unsigned)(int)(oyp ? gyp : 0.0f));
+  const idx_t ym = v.template part_y<SMALL>((unsigned)(int)(oym ? gym : 0.0f));
+  const idx_t z0 = v.template part_z<SMALL>((unsigned)(int)(oz0 ? gz0 : 0.0f));
+  const idx_t zp = v.template part_z<SMALL>((unsigned)(int)(ozp ? gzp : 0.0f));
+  const idx_t zm = v.template part_z<SMALL>((unsigned)(int)(ozm ? gzm : 0.0f));
+  const idx_t yz = y0 + z0, xz = x0 + z0, xy = x0 + y0;
+  // all six loads are issued before any is consumed
+  const uint32_t rxp = v.rec[xp + yz], rxm = v.rec[xm + yz];
+  const uint32_t ryp = v.rec[yp + xz], rym = v.rec[ym + xz];
+  const uint32_t rzp = v.rec[zp + xy], rzm = v.rec[zm + xy];
+  const bool byz = oy0 && oz0, bxz = ox0 && oz0, bxy = ox0 && oy0;
+  const int vxp = (oxp && byz) ? VolumePacked::value_of(rxp) : 0, vxm = (oxm && byz) ? VolumePacked::value_of(rxm) : 0;
+  const int vyp = (oyp && bxz) ? VolumePacked::value_of(ryp) : 0, vym = (oym && bxz) ? VolumePacked::value_of(rym) : 0;
+  const int vzp = (ozp && bxy) ? VolumePacked::value_of(rzp) : 0, vzm = (ozm && bxy) ? VolumePacked::value_of(rzm) : 0;
+  return f3{(float)(vxp - vxm), (float)(vyp - vym), (float)(vzp - vzm)};
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -153,15 +175,15 @@ __device__ __forceinline__ bool taps_are_voxel_neighbours(f3 p) {
 
 // one march step's classification on the packed volume: returns true on a Hit (and updates `color`),
 // otherwise `next_sd` is the SDF value for the next step
-template <bool USE_GRAD>
+template <bool USE_GRAD, bool SMALL = false>
 __device__ __forceinline__ bool classify_step(const VolumePacked &v, const TfDev &tf, f3 pos, uint32_t &color, int &next_sd) {
   if (USE_GRAD && !tf.opaque && (tf.literal_gradient_taps || !taps_are_voxel_neighbours(pos))) {
     const uint32_t r = v.fetch_f(pos.x, pos.y, pos.z);
-    const int gradient = (int)(short)f2i(length3(gradient_nn(v, pos)));
+    const int gradient = (int)(short)f2i(length3(gradient_nn<SMALL>(v, pos)));
     next_sd = VolumePacked::sdf_of(r) > 0 ? VolumePacked::sdf_of(r) : 0;
     return tf_eval(tf, VolumePacked::value_of(r), gradient, color);
   }
-  const unsigned q = v.step_f(pos.x, pos.y, pos.z);
+  const unsigned q = v.template step_marched<SMALL>(pos.x, pos.y, pos.z);  // both callers have just tested !exited_volume(pos)
   next_sd = (int)(q & 0x7Fu);
   if (!(q & 0x80u)) return false;
   const unsigned cls = VolumePacked::class_of(v.fetch_f(pos.x, pos.y, pos.z));

@@ -52,18 +52,17 @@ __device__ __forceinline__ unsigned lane_id() { return prefix_count(~0ull); }
 // volume + SDF + transfer function -> packed bricked records; one wave writes one 4x4x4 sub-brick
 // (256 contiguous bytes)
 __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
-  const size_t sub_id = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+  const size_t sub_id = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);  // 64 consecutive records of a brick
   const size_t n_sub = (size_t)a.NBX * a.NBY * a.NBZ * 8u;
   if (sub_id >= n_sub) return;
   const size_t brick = sub_id >> 3;
-  const unsigned sub = (unsigned)(sub_id & 7u);
   const int bx = (int)(brick % (size_t)a.NBX);
   const int by = (int)((brick / (size_t)a.NBX) % (size_t)a.NBY);
   const int bz = (int)(brick / ((size_t)a.NBX * (size_t)a.NBY));
   const unsigned lane = threadIdx.x & 63u;
-  const int x = bx * 8 + (int)(sub & 1u) * 4 + (int)(lane & 3u);
-  const int y = by * 8 + (int)((sub >> 1) & 1u) * 4 + (int)((lane >> 2) & 3u);
-  const int z = bz * 8 + (int)((sub >> 2) & 1u) * 4 + (int)(lane >> 4);
+  unsigned ix, iy, iz;
+  VolumePacked::inner_coords((unsigned)(sub_id & 7u) * 64u + lane, ix, iy, iz);
+  const int x = bx * 8 + (int)ix, y = by * 8 + (int)iy, z = bz * 8 + (int)iz;
   uint32_t r = 0u;
   uint8_t q = 0u;
   if (x < a.X && y < a.Y && z < a.Z) {
@@ -227,7 +226,7 @@ constexpr int kFixupDwords = 32;  // one record = 128 B: header[4] bv_before[3] 
 #ifndef CLVR_BOUNCE_WAVES_PER_SIMD
 #define CLVR_BOUNCE_WAVES_PER_SIMD 6  // measured: 4/5/6/8 waves per SIMD -> 2.47/2.47/2.38/3.07 ms per 16-pass launch (8 spills)
 #endif
-template <bool USE_GRAD, int MODE>
+template <bool USE_GRAD, int MODE, bool SMALL>
 __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(const RenderArgs a) {
   const VolumePacked vol = make_volume(a);
   // counters: [0] hits, [2] fix-up records, [3] fix-up overflow flag, [32 * (q + 1)] head of unit queue q
@@ -257,6 +256,10 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
   int sd = 0;              // SDF value for the next step of a MARCH lane
   int steps_left = 0;
   bool exhausted = false;  // wave-uniform: the queue has no more items
+#ifdef CLVR_BOUNCE_STATS
+  uint32_t st_step_iters = 0, st_step_lanes = 0, st_event_phases = 0, st_event_lanes = 0, st_refills = 0, st_refill_lanes = 0;
+  uint32_t st_ev_kind[4] = {0, 0, 0, 0};
+#endif
 
   for (;;) {
     // ---- refill: idle lanes pull consecutive items of the unit queues ---------------------------------
@@ -290,6 +293,9 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
       base = __shfl(base, 0);
       count = __shfl(count, 0);
       q_sel = __shfl(q_sel, 0);
+#ifdef CLVR_BOUNCE_STATS
+      st_refills += 1; st_refill_lanes += count;
+#endif
       if (count == 0u) {
         exhausted = true;  // every queue is dry
       } else if (st == ST_IDLE) {
@@ -337,6 +343,14 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
       }
     }
     if (__ballot(st != ST_IDLE) == 0ull) {
+#ifdef CLVR_BOUNCE_STATS
+      if (exhausted && lane == 0u) {
+        atomicAdd(&a.counters[8], st_step_iters); atomicAdd(&a.counters[9], st_step_lanes);
+        atomicAdd(&a.counters[10], st_event_phases); atomicAdd(&a.counters[11], st_event_lanes);
+        atomicAdd(&a.counters[12], st_refills); atomicAdd(&a.counters[13], st_refill_lanes);
+        for (int k = 0; k < 4; ++k) atomicAdd(&a.counters[14 + k], st_ev_kind[k]);
+      }
+#endif
       if (exhausted) break;  // nothing in flight and nothing left to fetch
       continue;              // every fetched sample was refused its token (or was padding): fetch again
     }
@@ -344,6 +358,9 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
     // ---- step phase: MARCH lanes step until fewer than kStepPhaseMinLanes are still marching -----
     if (__ballot(st == ST_MARCH) != 0ull) {
       do {
+#ifdef CLVR_BOUNCE_STATS
+        st_step_iters += 1; st_step_lanes += (uint32_t)__popcll(__ballot(st == ST_MARCH));
+#endif
         if (st == ST_MARCH) {
           const float step_size = cl_max((float)sd, 0.5f);
           ray.origin = ray.origin + ray.direction * step_size;
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
             st = ST_EVENT;
           } else {
             int next_sd;
-            const bool is_hit = classify_step<USE_GRAD>(vol, a.tf, ray.origin, color, next_sd);
+            const bool is_hit = classify_step<USE_GRAD, SMALL>(vol, a.tf, ray.origin, color, next_sd);
             if (is_hit) {
               ev = EV_HIT;
               st = ST_EVENT;
@@ -369,6 +386,13 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
     }
 
     // ---- event phase: every parked lane handles its event; the bounce is one shared block ---------
+#ifdef CLVR_BOUNCE_STATS
+    st_event_phases += 1; st_event_lanes += (uint32_t)__popcll(__ballot(st == ST_EVENT));
+    st_ev_kind[0] += (uint32_t)__popcll(__ballot(st == ST_EVENT && ev == EV_START));
+    st_ev_kind[1] += (uint32_t)__popcll(__ballot(st == ST_EVENT && ev == EV_EXIT));
+    st_ev_kind[2] += (uint32_t)__popcll(__ballot(st == ST_EVENT && ev == EV_HIT));
+    st_ev_kind[3] += (uint32_t)__popcll(__ballot(st == ST_EVENT && ev == EV_NONE));
+#endif
     if (st == ST_EVENT) {
       bool start_path = (ev == EV_START);  // begin distribution ray `o` from the primary hit
       bool bounce = false, from_hit = false;
@@ -417,7 +441,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
         start_path = true;
       } else if (ev == EV_HIT) {
         // ray_marching.cl:63-72: secondary hit -> bounce around the local normal, attenuate
-        bn = -normalize3(gradient_nn(vol, ray.origin));
+        bn = -normalize3(gradient_nn<SMALL>(vol, ray.origin));
         bbase = ray;
         bseed = seed + o + i;
         bounce = true;
@@ -479,7 +503,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
 
       if (st == ST_EVENT) {
         // start (or continue) a march: its first SDF read is at trunc(origin) (utility_ray.cl:148-150)
-        sd = (int)(vol.step_i(f2i(ray.origin.x), f2i(ray.origin.y), f2i(ray.origin.z)) & 0x7Fu);
+        sd = (int)(vol.template step_i<SMALL>(f2i(ray.origin.x), f2i(ray.origin.y), f2i(ray.origin.z)) & 0x7Fu);
         steps_left = 70;
         st = ST_MARCH;
       }
@@ -591,13 +615,21 @@ hipError_t launch_bounce(const RenderArgs &a, hipStream_t s) {
   const unsigned blocks = (unsigned)std::min<uint64_t>((waves_needed + 3u) / 4u, (uint64_t)a.bounce_max_blocks);
   const dim3 grid(blocks), block(256);
   const bool g = a.tf.uses_gradient != 0;
+  // fewer than 2^23 bricks (up to ~1600^3): every step byte has a 32-bit offset -> the march's 32-bit addressing
+  const bool small = (uint64_t)a.NBX * (uint64_t)a.NBY * (uint64_t)((a.Z + 7) / 8) < (1ull << 23);
+#define CLVR_LAUNCH_BOUNCE(G, M)                                                                    \
+  do {                                                                                              \
+    if (small) hipLaunchKernelGGL((k_bounce<G, M, true>), grid, block, 0, s, a);                   \
+    else hipLaunchKernelGGL((k_bounce<G, M, false>), grid, block, 0, s, a);                        \
+  } while (0)
   if (a.mode == CLWH_ACCUM_VOXEL_CACHE) {
-    if (g) hipLaunchKernelGGL((k_bounce<true, CLWH_ACCUM_VOXEL_CACHE>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_bounce<false, CLWH_ACCUM_VOXEL_CACHE>), grid, block, 0, s, a);
+    if (g) CLVR_LAUNCH_BOUNCE(true, CLWH_ACCUM_VOXEL_CACHE);
+    else CLVR_LAUNCH_BOUNCE(false, CLWH_ACCUM_VOXEL_CACHE);
   } else {
-    if (g) hipLaunchKernelGGL((k_bounce<true, CLWH_ACCUM_IMAGE_SPACE>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((k_bounce<false, CLWH_ACCUM_IMAGE_SPACE>), grid, block, 0, s, a);
+    if (g) CLVR_LAUNCH_BOUNCE(true, CLWH_ACCUM_IMAGE_SPACE);
+    else CLVR_LAUNCH_BOUNCE(false, CLWH_ACCUM_IMAGE_SPACE);
   }
+#undef CLVR_LAUNCH_BOUNCE
   return hipGetLastError();
 }
 
