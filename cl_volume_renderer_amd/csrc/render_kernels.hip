@@ -42,6 +42,16 @@ __device__ __forceinline__ VolumePacked make_volume(const RenderArgs &a) {
   return VolumePacked{a.packed, a.stepb, a.X, a.Y, a.Z, a.NBX, a.NBY};
 }
 
+// n / d and n % d for n, d < 2^24 through the float reciprocal (a 32-bit integer division is ~35 VALU instructions)
+__device__ __forceinline__ uint32_t udivmod24(uint32_t n, uint32_t d, uint32_t &rem) {
+  uint32_t q = (uint32_t)((float)n * __builtin_amdgcn_rcpf((float)d));  // the estimate is off by one at most in practice
+  int32_t r = (int32_t)(n - q * d);
+  while (r < 0) { q -= 1u; r += (int32_t)d; }
+  while (r >= (int32_t)d) { q += 1u; r -= (int32_t)d; }
+  rem = (uint32_t)r;
+  return q;
+}
+
 // number of set bits of `mask` below this lane
 __device__ __forceinline__ unsigned prefix_count(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
@@ -229,6 +239,11 @@ constexpr int kFixupDwords = 32;  // one record = 128 B: header[4] bv_before[3] 
 template <bool USE_GRAD, int MODE, bool SMALL>
 __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(const RenderArgs a) {
   const VolumePacked vol = make_volume(a);
+  // c / 255.0f for the 256 possible colour bytes (a correctly rounded division is ~10 VALU instructions, the
+  // kernel is VALU-issue bound, and every bounce needs four of them): one LDS read instead
+  __shared__ float div255[256];
+  div255[threadIdx.x] = (float)threadIdx.x / 255.0f;
+  __syncthreads();
   // counters: [0] hits, [2] fix-up records, [3] fix-up overflow flag, [32 * (q + 1)] head of unit queue q
   const uint32_t n_chunks = (a.n_hits + 63u) >> 6;
   const unsigned lane = lane_id();
@@ -305,10 +320,12 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
           // queue order: groups of `unit_group` chunks, inside a group seed-major -- the seeds of a chunk are
           // `unit_group` units apart (their accumulation atomics do not collide) yet close enough to find
           // each other's voxels still in L2
-          const uint32_t chunks_q = (n_chunks + NQ - 1u - q_sel) / NQ;
-          const uint32_t g = p / (G * S), r = p - g * (G * S);
+          // (units per queue stay below 2^24: launch_bounce checks)
+          const uint32_t chunks_q = (n_chunks + NQ - 1u - q_sel) / NQ;  // wave-uniform: scalar
+          uint32_t r, c_in;
+          const uint32_t g = udivmod24(p, G * S, r);
           const uint32_t in_group = min(G, chunks_q - g * G);  // the last group may be short
-          const uint32_t s = r / in_group, ch = g * G + (r - s * in_group);
+          const uint32_t s = udivmod24(r, in_group, c_in), ch = g * G + c_in;
           const uint32_t h = (q_sel + NQ * ch) * 64u + (item & 63u);
           if (h < a.n_hits) {
             fix = -1;
@@ -327,9 +344,9 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
             bool granted = true;
             if (MODE == CLWH_ACCUM_VOXEL_CACHE) granted = entry >= 0 && cache_take_token(a.cache, entry, 256u);
             if (granted) {
-              r_energy = (float)(color & 255u) / 255.0f;
-              g_energy = (float)((color >> 8) & 255u) / 255.0f;
-              b_energy = (float)((color >> 16) & 255u) / 255.0f;
+              r_energy = div255[color & 255u];
+              g_energy = div255[(color >> 8) & 255u];
+              b_energy = div255[(color >> 16) & 255u];
               bv_r = bv_g = bv_b = 0u;
               o = 1;
               st = ST_EVENT;
@@ -402,7 +419,8 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
 
       if (ev == EV_EXIT) {
         // ray_marching.cl:54-62: left the volume -> environment light ends this distribution ray
-        const float factor = 8.0f / (float)i;
+        // i is 8, 9 or 10 here (it starts at 8 and a path ends once it exceeds 10); the quotients are folded at compile time
+        const float factor = i == 8 ? 8.0f / 8.0f : (i == 9 ? 8.0f / 9.0f : (i == 10 ? 8.0f / 10.0f : 8.0f / (float)i));
         const float p_r = atten * r_energy, p_g = atten * g_energy, p_b = atten * b_energy;
         uint32_t light = 0u;
         bool certain = (fix == -1) && sample_environment_map_fast(a.env, a.env_w, a.env_h, ray.direction, light);
@@ -450,9 +468,9 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
         if (i > 10) {
           // third march of this distribution ray: the reference still multiplies the energies (they
           // carry into the next distribution ray) but its bounced ray is never marched
-          r_energy *= (float)(color & 255u) / 255.0f;
-          g_energy *= (float)((color >> 8) & 255u) / 255.0f;
-          b_energy *= (float)((color >> 16) & 255u) / 255.0f;
+          r_energy *= div255[color & 255u];
+          g_energy *= div255[(color >> 8) & 255u];
+          b_energy *= div255[(color >> 16) & 255u];
           bounce = false;
           o += 1;
           start_path = true;
@@ -483,7 +501,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
 
       if (bounce) {
         // ray_bounce_fake_reflectance, then origin += normal*2 (ray_marching.cl:48-50 / :65-67)
-        const float roughness = (float)(color >> 24) / 255.0f;
+        const float roughness = div255[color >> 24];
         Ray nr;
         nr.origin = bbase.origin + bbase.direction;
         nr.direction = hemisphere_reflective(gx, gy, bn, bseed, roughness);
@@ -491,9 +509,9 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
         const float d = fabsf(dot3(nr.direction, bn));
         if (from_hit) {
           atten *= d;
-          r_energy *= (float)(color & 255u) / 255.0f;
-          g_energy *= (float)((color >> 8) & 255u) / 255.0f;
-          b_energy *= (float)((color >> 16) & 255u) / 255.0f;
+          r_energy *= div255[color & 255u];
+          g_energy *= div255[(color >> 8) & 255u];
+          b_energy *= div255[(color >> 16) & 255u];
         } else {
           atten = d;
           i = 8;
@@ -614,6 +632,7 @@ hipError_t launch_bounce(const RenderArgs &a, hipStream_t s) {
   const uint64_t waves_needed = (total + 63u) / 64u;
   const unsigned blocks = (unsigned)std::min<uint64_t>((waves_needed + 3u) / 4u, (uint64_t)a.bounce_max_blocks);
   const dim3 grid(blocks), block(256);
+  if ((uint64_t)((a.n_hits + 63u) >> 6) * (uint64_t)a.n_seeds >= (1ull << 24)) return hipErrorInvalidValue;  // udivmod24
   const bool g = a.tf.uses_gradient != 0;
   // fewer than 2^23 bricks (up to ~1600^3): every step byte has a 32-bit offset -> the march's 32-bit addressing
   const bool small = (uint64_t)a.NBX * (uint64_t)a.NBY * (uint64_t)((a.Z + 7) / 8) < (1ull << 23);
