@@ -175,8 +175,19 @@ __device__ __forceinline__ bool taps_are_voxel_neighbours(f3 p) {
 
 // one march step's classification on the packed volume: returns true on a Hit (and updates `color`),
 // otherwise `next_sd` is the SDF value for the next step
-template <bool USE_GRAD, bool SMALL = false>
-__device__ __forceinline__ bool classify_step(const VolumePacked &v, const TfDev &tf, f3 pos, uint32_t &color, int &next_sd) {
+// the colour of a Hit found through the step byte: the voxel's class names the transfer-function rule
+__device__ __forceinline__ void hit_color(const VolumePacked &v, const TfDev &tf, f3 pos, uint32_t &color) {
+  const unsigned cls = VolumePacked::class_of(v.fetch_f(pos.x, pos.y, pos.z));
+  const TfRuleDev &rule = tf.rules[cls - 1u];
+  if (rule.flags & TF_WRITES_COLOR) color = rule.color;
+}
+
+// DEFER_COLOR: a Hit found through the step byte returns with `color_pending` set instead of fetching the record
+// for the rule's colour -- the persistent bounce kernel does that in its event phase (hit_color), where it costs one
+// pass per event phase rather than one per march iteration in which any lane happens to hit.
+template <bool USE_GRAD, bool SMALL = false, bool DEFER_COLOR = false>
+__device__ __forceinline__ bool classify_step(const VolumePacked &v, const TfDev &tf, f3 pos, uint32_t &color, int &next_sd,
+                                              bool *color_pending = nullptr) {
   if (USE_GRAD && !tf.opaque && (tf.literal_gradient_taps || !taps_are_voxel_neighbours(pos))) {
     const uint32_t r = v.fetch_f(pos.x, pos.y, pos.z);
     const int gradient = (int)(short)f2i(length3(gradient_nn<SMALL>(v, pos)));
@@ -186,9 +197,11 @@ __device__ __forceinline__ bool classify_step(const VolumePacked &v, const TfDev
   const unsigned q = v.template step_marched<SMALL>(pos.x, pos.y, pos.z);  // both callers have just tested !exited_volume(pos)
   next_sd = (int)(q & 0x7Fu);
   if (!(q & 0x80u)) return false;
-  const unsigned cls = VolumePacked::class_of(v.fetch_f(pos.x, pos.y, pos.z));
-  const TfRuleDev &rule = tf.rules[cls - 1u];
-  if (rule.flags & TF_WRITES_COLOR) color = rule.color;
+  if (DEFER_COLOR) {
+    *color_pending = true;
+    return true;
+  }
+  hit_color(v, tf, pos, color);
   return true;
 }
 

@@ -44,10 +44,14 @@ __device__ __forceinline__ VolumePacked make_volume(const RenderArgs &a) {
 
 // n / d and n % d for n, d < 2^24 through the float reciprocal (a 32-bit integer division is ~35 VALU instructions)
 __device__ __forceinline__ uint32_t udivmod24(uint32_t n, uint32_t d, uint32_t &rem) {
-  uint32_t q = (uint32_t)((float)n * __builtin_amdgcn_rcpf((float)d));  // the estimate is off by one at most in practice
-  int32_t r = (int32_t)(n - q * d);
-  while (r < 0) { q -= 1u; r += (int32_t)d; }
-  while (r >= (int32_t)d) { q += 1u; r -= (int32_t)d; }
+  // n < 2^24 and d < 2^24 convert exactly; the estimate's relative error is below 2^-22, so for the quotients met
+  // here (below 2^20, or d a power of two) it is off by at most one either way
+  uint32_t q = (uint32_t)((float)n * __builtin_amdgcn_rcpf((float)d));
+  uint32_t qd;
+  asm("v_mul_u32_u24 %0, %1, %2" : "=v"(qd) : "v"(q), "v"(d));
+  int32_t r = (int32_t)(n - qd);
+  if (r < 0) { q -= 1u; r += (int32_t)d; }
+  if (r >= (int32_t)d) { q += 1u; r -= (int32_t)d; }
   rem = (uint32_t)r;
   return q;
 }
@@ -186,7 +190,8 @@ __global__ __launch_bounds__(64) void k_primary(const RenderArgs a) {
 // 70 steps, or a freshly fetched item) parks in EVENT until the wave runs its event phase; IDLE
 // lanes have no item.
 enum : int { ST_IDLE = 0, ST_MARCH = 1, ST_EVENT = 2 };
-enum : int { EV_START = 3 };            // a freshly fetched item: start distribution ray 1
+enum : int { EV_START = 3,              // a freshly fetched item: start distribution ray 1
+             EV_HIT_COLOR_PENDING = 4 };  // a Hit whose rule colour is still to be fetched (classify_step DEFER_COLOR)
 
 // Image-space accumulation of one launch: a sample adds r | g<<16 | b<<32 | 1<<48 to its HIT's 64-bit
 // delta with ONE atomic (a launch has at most 64 seeds and a contribution is at most 255, so no field can
@@ -387,9 +392,10 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
             st = ST_EVENT;
           } else {
             int next_sd;
-            const bool is_hit = classify_step<USE_GRAD, SMALL>(vol, a.tf, ray.origin, color, next_sd);
+            bool pending = false;
+            const bool is_hit = classify_step<USE_GRAD, SMALL, true>(vol, a.tf, ray.origin, color, next_sd, &pending);
             if (is_hit) {
-              ev = EV_HIT;
+              ev = pending ? EV_HIT_COLOR_PENDING : EV_HIT;
               st = ST_EVENT;
             } else if (steps_left == 0) {
               ev = EV_NONE;
@@ -407,7 +413,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
     st_event_phases += 1; st_event_lanes += (uint32_t)__popcll(__ballot(st == ST_EVENT));
     st_ev_kind[0] += (uint32_t)__popcll(__ballot(st == ST_EVENT && ev == EV_START));
     st_ev_kind[1] += (uint32_t)__popcll(__ballot(st == ST_EVENT && ev == EV_EXIT));
-    st_ev_kind[2] += (uint32_t)__popcll(__ballot(st == ST_EVENT && ev == EV_HIT));
+    st_ev_kind[2] += (uint32_t)__popcll(__ballot(st == ST_EVENT && (ev == EV_HIT || ev == EV_HIT_COLOR_PENDING)));
     st_ev_kind[3] += (uint32_t)__popcll(__ballot(st == ST_EVENT && ev == EV_NONE));
 #endif
     if (st == ST_EVENT) {
@@ -457,7 +463,8 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
         }
         o += 1;
         start_path = true;
-      } else if (ev == EV_HIT) {
+      } else if (ev == EV_HIT || ev == EV_HIT_COLOR_PENDING) {
+        if (ev == EV_HIT_COLOR_PENDING) hit_color(vol, a.tf, ray.origin, color);
         // ray_marching.cl:63-72: secondary hit -> bounce around the local normal, attenuate
         bn = -normalize3(gradient_nn<SMALL>(vol, ray.origin));
         bbase = ray;
