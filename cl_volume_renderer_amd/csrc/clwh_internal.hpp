@@ -187,8 +187,8 @@ struct clwh_ctx {
   bool fixup_overflow_pending = false;
   // measured on MI355X (profiles/r01_tune_*.txt): a wave that runs its 64 samples to completion with
   // steps and events in separate wave-wide phases beats mid-flight refills (12.5 vs 7.6 Gsamples/s)
-  int32_t tune_step_min_lanes = 16;
-  int32_t tune_refill_min_lanes = 16;
+  int32_t tune_step_min_lanes = 0;    // 0: chosen per launch (launch_bounce)
+  int32_t tune_refill_min_lanes = 0;  // 0: chosen per launch (launch_bounce)
   int32_t tune_literal_gradient = 0;
   int32_t tune_unit_group = 8, tune_unit_affinity = 0, tune_unit_queues = 8;
   uint32_t tune_bounce_max_blocks = 2048;

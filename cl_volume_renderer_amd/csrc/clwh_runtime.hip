@@ -156,8 +156,8 @@ int clwh_ctx_create_on_stream(int device, void *hip_stream, clwh_ctx **out) {
   c->device = device;
   c->stream = (hipStream_t)hip_stream;
   c->own_stream = false;
-  if (const char *e = std::getenv("CLWH_TUNE_STEP")) c->tune_step_min_lanes = std::max(1, std::min(64, std::atoi(e)));
-  if (const char *e = std::getenv("CLWH_TUNE_REFILL")) c->tune_refill_min_lanes = std::max(1, std::min(64, std::atoi(e)));
+  if (const char *e = std::getenv("CLWH_TUNE_STEP")) c->tune_step_min_lanes = std::max(0, std::min(64, std::atoi(e)));
+  if (const char *e = std::getenv("CLWH_TUNE_REFILL")) c->tune_refill_min_lanes = std::max(0, std::min(64, std::atoi(e)));
   if (const char *e = std::getenv("CLWH_TUNE_LITERAL_GRADIENT")) c->tune_literal_gradient = std::atoi(e) != 0;
   if (const char *e = std::getenv("CLWH_TUNE_AFFINITY")) c->tune_unit_affinity = std::atoi(e);
   if (const char *e = std::getenv("CLWH_TUNE_QUEUES")) c->tune_unit_queues = std::max(1, std::min(8, std::atoi(e)));

@@ -632,13 +632,22 @@ hipError_t launch_primary(const RenderArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_bounce(const RenderArgs &a, hipStream_t s) {
+hipError_t launch_bounce(const RenderArgs &a_in, hipStream_t s) {
+  RenderArgs a = a_in;
   const uint64_t total = (uint64_t)a.n_hits * (uint64_t)a.n_seeds;
   if (total == 0) return hipSuccess;
   // persistent grid: enough waves to fill the chip (256 CUs x 32 waves), never more than the work
   const uint64_t waves_needed = (total + 63u) / 64u;
   const unsigned blocks = (unsigned)std::min<uint64_t>((waves_needed + 3u) / 4u, (uint64_t)a.bounce_max_blocks);
   const dim3 grid(blocks), block(256);
+  // Scheduling thresholds (0 = automatic).  A launch with only a few units per wave (one or a few passes) is
+  // bound by its longest dependent chain: every wave steps its samples to completion and refills when empty.
+  // A long launch is bound by VALU issue: lanes refill at 16 idle and the march phase ends at 16 marching lanes.
+  // Measured crossover on the headline scene: between 4 and 8 passes per launch = about 6 units per wave
+  // (profiles/r01_tune_refill_step_thresholds.txt).
+  const bool long_launch = waves_needed >= 6u * (uint64_t)blocks * 4u;
+  if (a.step_min_lanes <= 0) a.step_min_lanes = long_launch ? 16 : 1;
+  if (a.refill_min_lanes <= 0) a.refill_min_lanes = long_launch ? 16 : 64;
   if ((uint64_t)((a.n_hits + 63u) >> 6) * (uint64_t)a.n_seeds >= (1ull << 24)) return hipErrorInvalidValue;  // udivmod24
   const bool g = a.tf.uses_gradient != 0;
   // fewer than 2^23 bricks (up to ~1600^3): every step byte has a 32-bit offset -> the march's 32-bit addressing
