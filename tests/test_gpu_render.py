@@ -197,6 +197,36 @@ def test_several_seeds_in_one_launch(gpu_ctx, orc, mode):
     g.release()
 
 
+@pytest.mark.parametrize("refill,step", [(16, 16), (1, 48), (8, 1), (64, 1), (33, 64)])
+def test_scheduling_thresholds_do_not_change_results(orc, refill, step, monkeypatch):
+    """k_bounce's lane scheduling (idle lanes refill at `refill` idle lanes, the march phase ends below `step`
+    marching lanes; chosen per launch by default) is placement only: every setting gives the oracle's bits.
+    The knobs are read when a context is created."""
+    monkeypatch.setenv("CLWH_TUNE_REFILL", str(refill))
+    monkeypatch.setenv("CLWH_TUNE_STEP", str(step))
+    ctx = ffi.Context(0)
+    vol, sdf, env, tf = small_scene(orc, 48)
+    pos, d = look_at_centre(vol, [-20, 40, -20])
+    w, h = 160, 96
+    seeds = scene.glibc_rand(9)
+    o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (w, h), mode=orc.MODE_IMAGE_SPACE)
+    for s in seeds:
+        o.render(pos, d, s)
+    o.resolve(pos, d)
+    g = GpuScene(ctx, vol, sdf, env, tf, (w, h))
+    g.render(pos, d, seeds[0], mode=ffi.ACCUM_IMAGE_SPACE)   # one pass, with the per-pixel contribution output
+    first = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (w, h), mode=orc.MODE_IMAGE_SPACE)
+    first.render(pos, d, seeds[0])
+    assert np.array_equal(g.contrib.pull(), first.contrib)
+    g.render(pos, d, None, mode=ffi.ACCUM_IMAGE_SPACE, seeds=seeds[1:], debug=False)  # eight passes in one launch
+    hit = o.hit_index.reshape(h, w) >= 0
+    assert hit.sum() > 1000
+    assert np.array_equal(g.accum_row_major(0)[hit], o.accum[hit])
+    assert np.array_equal(g.frame.pull(), o.frame)
+    g.release()
+    ctx.destroy()
+
+
 def test_primary_hits_follow_camera_volume_and_tf_changes(gpu_ctx, orc):
     """the per-camera primary hits and the packed records are derived data: every input change must
     rebuild them (camera move, TF flush, SDF rebuild, volume push)."""
