@@ -1,9 +1,12 @@
 #include "hdre_loader.hpp"
 
+#include "png_reader.hpp"
+
 #include <cmath>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <iterator>
 #include <vector>
 
 namespace {
@@ -39,6 +42,21 @@ inline unsigned char to_ldr(float v) {
 image hdre_loader::load_file(const std::string path) {
   std::ifstream in(path, std::ios::in | std::ios::binary);
   if (in.fail()) fail(path, "cannot open");
+  {
+    // stb_image picks the decoder from the file's signature, not its name
+    unsigned char sig[8] = {0};
+    in.read(reinterpret_cast<char *>(sig), 8);
+    const size_t got = (size_t)in.gcount();
+    in.clear();
+    in.seekg(0);
+    if (png_has_signature(sig, got)) {
+      std::vector<unsigned char> file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+      image out;
+      std::string why;
+      if (!png_decode_rgba8(file, out.m_width, out.m_height, out.m_pixels, why)) fail(path, why.c_str());
+      return out;
+    }
+  }
   std::string line;
   std::getline(in, line);
   if (line != "#?RADIANCE" && line != "#?RGBE") fail(path, "not a Radiance HDR file");

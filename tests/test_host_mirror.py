@@ -242,6 +242,143 @@ def test_reference_sdf_test_program():
     assert "EVERYTHING FINE" in out.stdout and "13 layers" in out.stdout
 
 
+def _png_bytes(img, color, depth, interlace=False, palette=None, trns=None, filters=(0, 1, 2, 3, 4)):
+    """a small PNG writer for the reader's test: img [h][w][channels] of sample values at `depth` bits"""
+    import struct
+    import zlib
+
+    h, w, ch = img.shape
+
+    def pack_row(row):  # row [w][ch] -> bytes at the bit depth
+        flat = row.reshape(-1).astype(np.uint32)
+        if depth == 16:
+            return b"".join(struct.pack(">H", int(v)) for v in flat)
+        if depth == 8:
+            return bytes(int(v) for v in flat)
+        bits = "".join(format(int(v), "0%db" % depth) for v in flat)
+        bits += "0" * (-len(bits) % 8)
+        return bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8))
+
+    bpp = max(1, ch * depth // 8)
+
+    def filter_rows(rows):
+        out, prev = b"", None
+        for y, cur in enumerate(rows):
+            t = filters[y % len(filters)]
+            f = bytearray(len(cur))
+            for i in range(len(cur)):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i] if prev is not None else 0
+                c = prev[i - bpp] if (prev is not None and i >= bpp) else 0
+                if t == 0:
+                    pr = 0
+                elif t == 1:
+                    pr = a
+                elif t == 2:
+                    pr = b
+                elif t == 3:
+                    pr = (a + b) >> 1
+                else:
+                    pp = a + b - c
+                    pa, pb, pc = abs(pp - a), abs(pp - b), abs(pp - c)
+                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                f[i] = (cur[i] - pr) & 255
+            out += bytes([t]) + bytes(f)
+            prev = cur
+        return out
+
+    if interlace:
+        raw = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = img[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += filter_rows([pack_row(r) for r in sub])
+    else:
+        raw = filter_rows([pack_row(r) for r in img])
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+
+    z = zlib.compress(raw, 6)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(palette.reshape(-1).tolist()))
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    half = len(z) // 2  # two IDAT chunks: the stream may be split anywhere
+    return out + chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")
+
+
+PNG_CASES = [  # colour type, bit depth, interlace
+    (2, 8, False), (6, 8, False), (0, 8, False), (4, 8, False), (3, 8, False), (2, 16, False), (6, 16, True),
+    (0, 1, False), (0, 2, True), (0, 4, False), (3, 2, False), (3, 4, True), (2, 8, True), (0, 16, False), (4, 16, True),
+]
+
+
+@pytest.mark.parametrize("color,depth,interlace", PNG_CASES)
+def test_env_map_loader_decodes_png(tmp_path, color, depth, interlace):
+    """PNG environment maps (the reference loads any stb_image format with 4 requested channels,
+    app/hdre_loader.cpp:13): every colour type / bit depth, all five filters, Adam7, PLTE + tRNS, two IDAT
+    chunks; expected RGBA8 stated in numpy from the PNG specification (lossless format)."""
+    L = _host()
+    L.clvr_host_hdr_probe.restype = C.c_longlong
+    L.clvr_host_hdr_probe.argtypes = [C.c_char_p, C.POINTER(C.c_uint), C.c_void_p, C.c_longlong]
+    rng = np.random.default_rng(color * 100 + depth + interlace)
+    w, h = 37, 19
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color]
+    palette = trns = None
+    if color == 3:
+        n_pal = 1 << depth
+        palette = rng.integers(0, 256, (n_pal, 3)).astype(np.uint8)
+        trns = rng.integers(0, 256, n_pal // 2).astype(np.uint8).tolist()  # shorter than the palette: the rest is opaque
+        img = rng.integers(0, n_pal, (h, w, 1))
+    else:
+        img = rng.integers(0, 1 << depth, (h, w, ch))
+        img[:, :5] = img[:1, :1]  # flat areas for the filters
+    if color == 0 and depth <= 8:
+        key = int(img[3, 7, 0])
+        trns = [0, key]  # one fully transparent grey level
+    if color == 2 and depth == 8:
+        key3 = img[2, 9].tolist()
+        trns = [0, key3[0], 0, key3[1], 0, key3[2]]
+    data = _png_bytes(img, color, depth, interlace, palette, trns)
+    path = str(tmp_path / "env.png")
+    open(path, "wb").write(data)
+
+    def to8(v):
+        if depth == 16:
+            return v >> 8
+        if depth == 8:
+            return v
+        return v * {1: 255, 2: 85, 4: 17}[depth]
+
+    want = np.zeros((h, w, 4), np.uint8)
+    want[..., 3] = 255
+    if color == 3:
+        want[..., :3] = palette[img[..., 0]]
+        a = np.full(1 << depth, 255)
+        a[: len(trns)] = trns
+        want[..., 3] = a[img[..., 0]]
+    elif color == 0:
+        want[..., :3] = to8(img[..., :1])
+        if trns is not None:
+            want[..., 3] = np.where(img[..., 0] == key, 0, 255)
+    elif color == 4:
+        want[..., :3] = to8(img[..., :1])
+        want[..., 3] = to8(img[..., 1])
+    elif color == 2:
+        want[..., :3] = to8(img)
+        if trns is not None:
+            want[..., 3] = np.where((img == np.array(key3)).all(-1), 0, 255)
+    else:
+        want[...] = to8(img)
+    dims = (C.c_uint * 2)()
+    out = np.zeros((h, w, 4), np.uint8)
+    n = L.clvr_host_hdr_probe(path.encode(), dims, out.ctypes.data, out.nbytes)
+    assert n == out.nbytes and (dims[0], dims[1]) == (w, h)
+    assert np.array_equal(out, want)
+
+
 @pytest.mark.parametrize("rle,w", [(True, 64), (False, 64), (True, 5), (True, 300)])
 def test_hdre_loader_decodes_radiance_files(tmp_path, rle, w):
     """app/hdre_loader.cpp mirror (CPU only): RGBE decode + gamma-2.2 LDR conversion; parity unpinned (the
