@@ -1,5 +1,6 @@
 #!/bin/bash
-# tools/profile_pmc_extra.sh TAG -- extra PMC passes for k_bounce (issue mix, TA/TCP stalls, TLB); run on the GPU box.
+# tools/profile_pmc_extra.sh TAG -- extra PMC passes for k_bounce (issue mix); run on the GPU box.
+# (A pass with TCP_* / TA_* counters aborted inside rocprofv3 on this pool and is not part of the script.)
 set -o pipefail
 TAG=${1:-extra}; shift
 OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out/pmcx_$TAG
@@ -14,8 +15,6 @@ while read -r SET; do
 done <<'SETS'
 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VALU
 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32
-TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum
-TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TA_TA_BUSY_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum
 SETS
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
