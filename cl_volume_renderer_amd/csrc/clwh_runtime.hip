@@ -647,6 +647,8 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     ctx->primary_valid = true;
   }
   a.n_hits = ctx->primary_n_hits;
+  // the bounce kernel's queue arithmetic needs ceil(hits / 64) x seeds below 2^24 (64 seeds: 16.7 M hit pixels)
+  if ((uint64_t)((a.n_hits + 63u) >> 6) * (uint64_t)a.n_seeds >= (1ull << 24)) return CLWH_ERR_INVALID_VALUE;
 
   // ---- the pass: every (hit, seed) item
   // fix-up records for environment lookups the fast path cannot certify: room for 1/16 of the items;

@@ -152,7 +152,9 @@ typedef struct clwh_render_desc {
   clwh_mem *contrib;        /* optional uint32[4] per pixel, row-major: r,g,b,granted (parity tests; one seed) */
   int32_t n_seeds;          /* > 0: render n_seeds passes (<= CLWH_MAX_SEEDS) in ONE launch, seeds[] below; the
                                result equals n_seeds consecutive single-seed calls (image-space mode always; voxel
-                               cache mode while no voxel reaches the 256-token cap) */
+                               cache mode while no voxel reaches the 256-token cap).  ceil(hit pixels / 64) x
+                               n_seeds must stay below 2^24 (64 seeds: 16.7 M hit pixels), else
+                               CLWH_ERR_INVALID_VALUE: use fewer seeds per launch */
   int32_t seeds[64];
 } clwh_render_desc;
 #define CLWH_MAX_SEEDS 64
