@@ -11,12 +11,14 @@
 //                                                hits are compacted into 64-byte records with a
 //                                                wave ballot + prefix (one atomic per wave);
 //                                                misses keep their environment colour
-//   k_bounce   (every pass, 1..16 seeds)         persistent waves pull (hit, seed) items from a work
-//                                                queue; each lane runs the sample's two
-//                                                distribution rays as a small state machine; lanes
-//                                                that finish are refilled by ballot/prefix
-//                                                compaction; march steps and event handling run in
-//                                                separate wave-wide phases so both stay dense
+//   k_bounce   (every launch, 1..64 seeds)       persistent waves pull (hit, seed) items from eight
+//                                                work queues; each lane runs the sample's two
+//                                                distribution rays as a small state machine; idle
+//                                                lanes are refilled by ballot/prefix compaction once
+//                                                enough of them are idle; march steps and event
+//                                                handling run in separate wave-wide phases
+//   k_env_fixup / k_commit                       exact environment lookups the fast path could not
+//                                                certify; per-hit sums -> float4 accumulator
 //   k_resolve  (when a frame is wanted)          read the accumulator AFTER the pass (deterministic;
 //                                                one legal outcome of the reference's race, SURVEY
 //                                                fact 4), tone curve, RGBA8
