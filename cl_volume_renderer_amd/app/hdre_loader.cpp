@@ -69,6 +69,14 @@ image hdre_loader::load_file(const std::string path) {
   if (std::sscanf(line.c_str(), "-Y %d +X %d", &height, &width) != 2 || width <= 0 || height <= 0)
     fail(path, "unsupported data layout");
 
+  {
+    // a corrupt resolution line must not turn into a huge allocation: a run-length scanline expands at most 64:1
+    const std::streamoff here = in.tellg();
+    in.seekg(0, std::ios::end);
+    const unsigned long long remaining = (unsigned long long)(in.tellg() - here);
+    in.seekg(here);
+    if ((unsigned long long)width * (unsigned long long)height * 4ull > remaining * 64ull + 64ull) fail(path, "resolution exceeds the data");
+  }
   std::vector<unsigned char> rgbe((size_t)width * height * 4);
   auto get = [&]() -> int { return in.get(); };
   bool flat = width < 8 || width >= 32768;

@@ -30,6 +30,18 @@ std::string trim(const std::string &s) {
   return b == std::string::npos ? std::string() : s.substr(b, e - b + 1);
 }
 
+// numbers of the header: a malformed one is a format violation (fail hard), not an uncaught exception
+unsigned parse_size(const std::string &word) {
+  if (word.empty() || word.find_first_not_of("0123456789") != std::string::npos || word.size() > 9) fail("does not declare sizes correctly.");
+  return (unsigned)std::stoul(word);
+}
+float parse_float(const std::string &word) {
+  char *end = nullptr;
+  const float v = std::strtof(word.c_str(), &end);
+  if (end == word.c_str() || *end != '\0') fail("does not declare space direction correctly.");
+  return v;
+}
+
 // "(a,b,c)" -> component `which`
 float vector_component(const std::string &token, int which) {
   std::string inner = token;
@@ -37,7 +49,7 @@ float vector_component(const std::string &token, int which) {
   if (!inner.empty() && inner.back() == ')') inner.pop_back();
   const auto parts = split(inner, ',');
   if ((int)parts.size() != 3) fail("does not declare space direction correctly.");
-  return std::stof(parts[which]);
+  return parse_float(parts[which]);
 }
 
 }  // namespace
@@ -72,9 +84,9 @@ nrrd_header nrrd_loader::load_header(const std::string &path) {
       if (words[0] != "3") fail("not using dimension of 3.");
     } else if (tag == "sizes") {
       if (words.size() != 3) fail("does not declare sizes correctly.");
-      h.x = (unsigned)std::stoul(words[0]);
-      h.y = (unsigned)std::stoul(words[1]);
-      h.z = (unsigned)std::stoul(words[2]);
+      h.x = parse_size(words[0]);
+      h.y = parse_size(words[1]);
+      h.z = parse_size(words[2]);
     } else if (tag == "space directions") {
       if (words.size() != 3) fail("does not declare space direction correctly.");
       const float sx = vector_component(words[0], 0), sy = vector_component(words[1], 1), sz = vector_component(words[2], 2);
@@ -93,8 +105,11 @@ volume_block nrrd_loader::load_file(const std::string path) {
   const nrrd_header h = load_header(path);
   const std::uint64_t voxels = (std::uint64_t)h.x * h.y * h.z;
   if (voxels == 0) fail("does not declare sizes correctly.");
-  std::vector<short> data(voxels);
   const std::uint64_t want_bytes = voxels * sizeof(short);
+  // a corrupt header must not turn into a terabyte allocation: deflate expands at most 1032:1
+  const std::uint64_t payload = h.data_end - h.data_start;
+  if (h.raw ? want_bytes > payload : want_bytes / 1032u > payload + 64u) fail("declares sizes its payload cannot hold.");
+  std::vector<short> data(voxels);
 
   std::ifstream in(path, std::ios::in | std::ios::binary);
   in.seekg((std::streamoff)h.data_start);

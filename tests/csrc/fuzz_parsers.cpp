@@ -10,6 +10,11 @@
 #include <string>
 #include <vector>
 
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include "../../cl_volume_renderer_amd/app/hdre_loader.hpp"
+#include "../../cl_volume_renderer_amd/app/nrrd_loader.hpp"
 #include "../../cl_volume_renderer_amd/app/png_reader.hpp"
 #include "../../include/clwh.h"
 
@@ -46,11 +51,58 @@ void mutate(std::vector<unsigned char> &b) {
 }
 }  // namespace
 
-// usage: fuzz_parsers <iterations> png <file>... | tf <file>...
+// The file loaders follow the reference's fail-hard convention (message + exit(1)), so each mutated file is loaded
+// in a forked child: exit status 0 or 1 is fine, anything else (a sanitizer report exits with ASAN_OPTIONS'
+// exitcode, UBSan aborts, a crash is a signal) fails the run.
+int fuzz_loader(const std::string &kind, long iters, const std::vector<std::vector<unsigned char>> &seeds, const char *scratch) {
+  long ok = 0, rejected = 0;
+  for (long it = 0; it < iters; ++it) {
+    std::vector<unsigned char> b = seeds[rnd() % seeds.size()];
+    if (it >= (long)seeds.size()) mutate(b);
+    {
+      std::ofstream out(scratch, std::ios::binary | std::ios::trunc);
+      out.write(reinterpret_cast<const char *>(b.data()), (std::streamsize)b.size());
+    }
+    const pid_t pid = fork();
+    if (pid < 0) return 2;
+    if (pid == 0) {
+      std::fclose(stderr);  // the loaders' own error messages
+      if (kind == "nrrd") {
+        nrrd_loader l;
+        volume_block v = l.load_file(scratch);
+        (void)v;
+      } else {
+        hdre_loader l;
+        image im = l.load_file(scratch);
+        if (im.m_pixels.size() != (size_t)im.m_width * im.m_height * 4) _exit(3);
+      }
+      _exit(0);
+    }
+    int status = 0;
+    waitpid(pid, &status, 0);
+    if (WIFEXITED(status) && WEXITSTATUS(status) == 0) ++ok;
+    else if (WIFEXITED(status) && WEXITSTATUS(status) == 1) ++rejected;
+    else {
+      std::fprintf(stderr, "iteration %ld: child status 0x%x (input kept in %s)\n", it, status, scratch);
+      return 1;
+    }
+  }
+  std::printf("%ld iterations, %ld accepted, %ld rejected\n", iters, ok, rejected);
+  return 0;
+}
+
+// usage: fuzz_parsers <iterations> png|tf <file>...   |   fuzz_parsers <iterations> nrrd|hdr <scratch file> <file>...
 int main(int argc, char **argv) {
   if (argc < 4) return 2;
   const long iters = std::atol(argv[1]);
-  const bool png = std::string(argv[2]) == "png";
+  const std::string kind = argv[2];
+  if (kind == "nrrd" || kind == "hdr") {
+    if (argc < 5) return 2;
+    std::vector<std::vector<unsigned char>> seeds;
+    for (int i = 4; i < argc; ++i) seeds.push_back(read_file(argv[i]));
+    return fuzz_loader(kind, iters, seeds, argv[3]);
+  }
+  const bool png = kind == "png";
   std::vector<std::vector<unsigned char>> seeds;
   for (int i = 3; i < argc; ++i) seeds.push_back(read_file(argv[i]));
   long accepted = 0;

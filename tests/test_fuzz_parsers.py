@@ -19,8 +19,11 @@ def fuzzer(tmp_path_factory):
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            os.path.join(ROOT, "tests", "csrc", "fuzz_parsers.cpp"),
                            os.path.join(ROOT, "cl_volume_renderer_amd", "app", "png_reader.cpp"),
+                           os.path.join(ROOT, "cl_volume_renderer_amd", "app", "hdre_loader.cpp"),
+                           os.path.join(ROOT, "cl_volume_renderer_amd", "app", "nrrd_loader.cpp"),
                            os.path.join(ROOT, "cl_volume_renderer_amd", "csrc", "tf_parse.cpp"),
-                           "-I", os.path.join(ROOT, "include"), "-lz", "-o", exe])
+                           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "cl_volume_renderer_amd", "app"),
+                           "-lz", "-o", exe])
     return exe
 
 
@@ -73,3 +76,40 @@ def test_tf_parser_survives_mutated_sources(fuzzer, tmp_path):
     out = subprocess.run([fuzzer, "200000", "tf"] + paths, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     assert int(out.stdout.split(",")[1].split()[0]) >= len(paths)
+
+
+def _loader_env():
+    env = dict(os.environ)
+    env["ASAN_OPTIONS"] = "exitcode=77:detect_leaks=0"  # 1 is the loaders' own fail-hard status
+    return env
+
+
+def test_nrrd_loader_survives_mutated_files(fuzzer, tmp_path):
+    """the fail-hard loaders run in forked children: exit 0 (loaded) or 1 (rejected) only"""
+    rng = np.random.default_rng(3)
+    vol = rng.integers(-1000, 3000, (6, 5, 7)).astype(np.int16)
+    seeds = []
+    for k, gz in enumerate((True, False)):
+        p = str(tmp_path / ("v%d.nrrd" % k))
+        scene.write_nrrd(p, vol, use_gzip=gz)
+        seeds.append(p)
+    seeds.append(os.path.join(ROOT, "tests", "golden", "sdf_testdata.nrrd"))
+    out = subprocess.run([fuzzer, "3000", "nrrd", str(tmp_path / "scratch.nrrd")] + seeds, capture_output=True, text=True,
+                         timeout=900, env=_loader_env())
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert int(out.stdout.split(",")[1].split()[0]) >= len(seeds)
+
+
+def test_hdr_loader_survives_mutated_files(fuzzer, tmp_path):
+    rng = np.random.default_rng(4)
+    seeds = []
+    for k, (w, rle) in enumerate(((40, True), (40, False), (5, True))):
+        rgb = (rng.random((9, w, 3), dtype=np.float32) * 2).astype(np.float32)
+        rgb[:, : w // 2] = rgb[:, :1]
+        p = str(tmp_path / ("e%d.hdr" % k))
+        scene.write_hdr(p, scene.float_to_rgbe(rgb), rle=rle)
+        seeds.append(p)
+    out = subprocess.run([fuzzer, "3000", "hdr", str(tmp_path / "scratch.hdr")] + seeds, capture_output=True, text=True,
+                         timeout=900, env=_loader_env())
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert int(out.stdout.split(",")[1].split()[0]) >= len(seeds)
