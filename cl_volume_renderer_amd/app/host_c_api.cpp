@@ -97,6 +97,17 @@ long long clvr_host_nrrd_probe(const char *path, unsigned dims[3], long long *ch
   *checksum = sum;
   return (long long)b.m_voxels.size();
 }
+// nrrd_loader::load_file, whole result (no device involved): counts, voxel sizes, voxels
+long long clvr_host_nrrd_load(const char *path, unsigned counts[3], float sizes[3], short *out, long long cap_voxels) {
+  nrrd_loader loader;
+  volume_block b = loader.load_file(path);
+  counts[0] = b.m_voxel_count_x; counts[1] = b.m_voxel_count_y; counts[2] = b.m_voxel_count_z;
+  sizes[0] = b.m_voxel_size_x; sizes[1] = b.m_voxel_size_y; sizes[2] = b.m_voxel_size_z;
+  const long long n = (long long)b.m_voxels.size();
+  if (n > cap_voxels) return -n;
+  std::memcpy(out, b.m_voxels.data(), (size_t)n * sizeof(short));
+  return n;
+}
 // hdre_loader::load_file probe (no device involved): decodes into `out` (w*h*4 bytes) when it is large enough
 long long clvr_host_hdr_probe(const char *path, unsigned dims[2], unsigned char *out, long long out_bytes) {
   hdre_loader loader;

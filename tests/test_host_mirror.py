@@ -381,8 +381,8 @@ def test_env_map_loader_decodes_png(tmp_path, color, depth, interlace):
 
 @pytest.mark.parametrize("rle,w", [(True, 64), (False, 64), (True, 5), (True, 300)])
 def test_hdre_loader_decodes_radiance_files(tmp_path, rle, w):
-    """app/hdre_loader.cpp mirror (CPU only): RGBE decode + gamma-2.2 LDR conversion; parity unpinned (the
-    reference ships no .hdr file), checked against the numpy statement of the same formula."""
+    """app/hdre_loader.cpp mirror (CPU only): RGBE decode + gamma-2.2 LDR conversion, checked against the numpy
+    statement of the same formula (tests/test_ref_hostio.py checks it against the reference's own loader)."""
     L = _host()
     L.clvr_host_hdr_probe.restype = C.c_longlong
     L.clvr_host_hdr_probe.argtypes = [C.c_char_p, C.POINTER(C.c_uint), C.c_void_p, C.c_longlong]

@@ -1,0 +1,158 @@
+"""-m "not gpu": this project's host-side mirrors against the REFERENCE's own code.
+
+oracle/ref/Makefile compiles the reference's app/hdre_loader.cpp (with the stb_image.h it vendors), app/nrrd_loader.cpp
+and common.hpp's Position3D from /root/reference where they lie into oracle/_ref/libref_hostio.so; the tests below
+feed both sides the same files / angles and require identical bytes.  Skipped when neither the library nor the
+reference tree is there (the reference does not travel; the prebuilt library does)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from cl_volume_renderer_amd import scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_LIB = os.path.join(ROOT, "oracle", "_ref", "libref_hostio.so")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not os.path.exists(REF_LIB):
+        if not os.path.isdir("/root/reference/app"):
+            pytest.skip("oracle/_ref/libref_hostio.so not built and no reference tree to build it from")
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle", "ref"), "-s"])
+    L = C.CDLL(REF_LIB)
+    L.ref_env_load.restype = C.c_longlong
+    L.ref_env_load.argtypes = [C.c_char_p, C.POINTER(C.c_uint), C.c_void_p, C.c_longlong]
+    L.ref_nrrd_load.restype = C.c_longlong
+    L.ref_nrrd_load.argtypes = [C.c_char_p, C.POINTER(C.c_uint), C.POINTER(C.c_float), C.c_void_p, C.c_longlong]
+    L.ref_camera_direction.argtypes = [C.c_double, C.c_double, C.POINTER(C.c_float)]
+    return L
+
+
+@pytest.fixture(scope="module")
+def mine():
+    from tests.test_host_mirror import _host
+
+    L = _host()
+    L.clvr_host_hdr_probe.restype = C.c_longlong
+    L.clvr_host_hdr_probe.argtypes = [C.c_char_p, C.POINTER(C.c_uint), C.c_void_p, C.c_longlong]
+    L.clvr_host_nrrd_load.restype = C.c_longlong
+    L.clvr_host_nrrd_load.argtypes = [C.c_char_p, C.POINTER(C.c_uint), C.POINTER(C.c_float), C.c_void_p, C.c_longlong]
+    return L
+
+
+def _both_env(ref, mine, path, w, h):
+    out_r = np.zeros((h, w, 4), np.uint8)
+    out_m = np.zeros((h, w, 4), np.uint8)
+    dr, dm = (C.c_uint * 2)(), (C.c_uint * 2)()
+    assert ref.ref_env_load(path.encode(), dr, out_r.ctypes.data, out_r.nbytes) == out_r.nbytes
+    assert mine.clvr_host_hdr_probe(path.encode(), dm, out_m.ctypes.data, out_m.nbytes) == out_m.nbytes
+    assert (dr[0], dr[1]) == (dm[0], dm[1]) == (w, h)
+    return out_r, out_m
+
+
+@pytest.mark.parametrize("rle,w,h", [(True, 64, 17), (False, 64, 17), (True, 5, 3), (True, 300, 9), (True, 1024, 4)])
+def test_hdr_environment_maps_decode_like_the_reference(ref, mine, tmp_path, rle, w, h):
+    """Radiance .hdr -> gamma-2.2 RGBA8 (app/hdre_loader.cpp:7-24 through stb_image): pins app/hdre_loader.cpp here"""
+    rng = np.random.default_rng(w * 7 + h)
+    rgb = (rng.random((h, w, 3), dtype=np.float32) ** 3 * 6.0).astype(np.float32)
+    rgb[:, : w // 3] = rgb[:, :1]
+    rgb[0, 0] = 0.0
+    rgb[-1, -1] = [1e-6, 300.0, 1.0]  # tiny and over-range values
+    path = str(tmp_path / "env.hdr")
+    scene.write_hdr(path, scene.float_to_rgbe(rgb), rle=rle)
+    out_r, out_m = _both_env(ref, mine, path, w, h)
+    assert np.array_equal(out_m, out_r)
+    assert out_r[..., :3].std() > 10
+
+
+def test_png_environment_maps_decode_like_the_reference(ref, mine, tmp_path):
+    """every PNG flavour of tests/test_host_mirror.py through the reference's stb_image: pins app/png_reader.cpp"""
+    from tests.test_host_mirror import PNG_CASES, _png_bytes
+
+    for color, depth, interlace in PNG_CASES:
+        rng = np.random.default_rng(color * 100 + depth + interlace)
+        w, h = 37, 19
+        ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color]
+        palette = trns = None
+        if color == 3:
+            n_pal = 1 << depth
+            palette = rng.integers(0, 256, (n_pal, 3)).astype(np.uint8)
+            trns = rng.integers(0, 256, n_pal // 2).astype(np.uint8).tolist()
+            img = rng.integers(0, n_pal, (h, w, 1))
+        else:
+            img = rng.integers(0, 1 << depth, (h, w, ch))
+        if color == 0:
+            trns = [0, int(img[3, 7, 0])] if depth <= 8 else [int(img[3, 7, 0]) >> 8, int(img[3, 7, 0]) & 255]
+        if color == 2:
+            k = img[2, 9].tolist()
+            trns = [k[0] >> 8, k[0] & 255, k[1] >> 8, k[1] & 255, k[2] >> 8, k[2] & 255]
+        path = str(tmp_path / ("c%d_d%d_i%d.png" % (color, depth, interlace)))
+        open(path, "wb").write(_png_bytes(img, color, depth, interlace, palette, trns))
+        out_r, out_m = _both_env(ref, mine, path, w, h)
+        assert np.array_equal(out_m, out_r), (color, depth, interlace)
+
+
+def _both_nrrd(ref, mine, path, n):
+    res = []
+    for fn in (ref.ref_nrrd_load, mine.clvr_host_nrrd_load):
+        counts, sizes = (C.c_uint * 3)(), (C.c_float * 3)()
+        out = np.zeros(n, np.int16)
+        got = fn(path.encode(), counts, sizes, out.ctypes.data, n)
+        assert got == n
+        res.append((tuple(counts), tuple(sizes), out))
+    return res
+
+
+@pytest.mark.parametrize("gz", [True, False])
+def test_nrrd_volumes_load_like_the_reference(ref, mine, tmp_path, gz):
+    """app/nrrd_loader.cpp: counts, relative voxel sizes and every voxel"""
+    rng = np.random.default_rng(11)
+    vol = rng.integers(-2000, 4000, (9, 14, 23)).astype(np.int16)
+    path = str(tmp_path / "v.nrrd")
+    scene.write_nrrd(path, vol, use_gzip=gz)
+    (cr, sr, vr), (cm, sm, vm) = _both_nrrd(ref, mine, path, vol.size)
+    assert cr == cm == (23, 14, 9)
+    assert sr == sm
+    assert np.array_equal(vr, vm) and np.array_equal(vm, vol.reshape(-1))
+
+
+def test_nrrd_anisotropic_header_and_the_reference_test_block(ref, mine, tmp_path):
+    golden = os.path.join(ROOT, "tests", "golden", "sdf_testdata.nrrd")
+    dims = scene.read_nrrd(golden).shape  # the reference's own test volume (tests/sdf/testdata.nrrd)
+    n = int(np.prod(dims))
+    (cr, sr, vr), (cm, sm, vm) = _both_nrrd(ref, mine, golden, n)
+    assert cr == cm == (dims[2], dims[1], dims[0]) and sr == sm and np.array_equal(vr, vm)
+    # anisotropic spacing: voxel sizes are kept relative to x
+    vol = np.arange(4 * 3 * 5, dtype=np.int16).reshape(4, 3, 5)
+    path = str(tmp_path / "a.nrrd")
+    hdr = ("NRRD0004\n# comment\ntype: short\ndimension: 3\nsizes: 5 3 4\n"
+           "space directions: (0.5,0,0) (0,0.75,0) (0,0,2.5)\nendian: little\nencoding: raw\n\n")
+    open(path, "wb").write(hdr.encode() + vol.astype("<i2").tobytes())
+    (cr, sr, vr), (cm, sm, vm) = _both_nrrd(ref, mine, path, vol.size)
+    assert cr == cm == (5, 3, 4)
+    assert sr == sm and sr[0] == 1.0 and sr[1] == pytest.approx(1.5) and sr[2] == pytest.approx(5.0)
+    assert np.array_equal(vr, vm)
+
+
+def test_camera_direction_matches_position3d(ref, mine, orc):
+    """Position3D(alpha, beta, 0, {1,0,0}) (app/common.hpp, renderer.cpp:140): the python helper, the oracle's
+    orc_camera_direction and the C++ host mirror all give the reference's bits"""
+    rng = np.random.default_rng(2)
+    angles = [(0.9, 6.183), (0.0, 0.0), (0.3, 6.1), (-1.2, 3.0)] + [tuple(rng.uniform(-7, 7, 2)) for _ in range(200)]
+    mine.clvr_host_camera_direction.argtypes = [C.c_float, C.c_float, C.POINTER(C.c_float)]
+    for a, b in angles:
+        a32, b32 = np.float32(a), np.float32(b)  # ui_state keeps the look angles as floats
+        want = (C.c_float * 3)()
+        ref.ref_camera_direction(float(a32), float(b32), want)
+        want = np.array(want[:], np.float32)
+        assert np.array_equal(scene.camera_direction(a32, b32), want), (a, b)
+        got = (C.c_float * 3)()
+        mine.clvr_host_camera_direction(a32, b32, got)
+        assert np.array_equal(np.array(got[:], np.float32), want)
+        o = (C.c_float * 3)()
+        orc.lib().orc_camera_direction(float(a32), float(b32), o)
+        assert np.array_equal(np.array(o[:], np.float32), want)
