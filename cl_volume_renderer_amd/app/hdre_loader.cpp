@@ -1,5 +1,6 @@
 #include "hdre_loader.hpp"
 
+#include "jpeg_reader.hpp"
 #include "png_reader.hpp"
 
 #include <cmath>
@@ -49,11 +50,14 @@ image hdre_loader::load_file(const std::string path) {
     const size_t got = (size_t)in.gcount();
     in.clear();
     in.seekg(0);
-    if (png_has_signature(sig, got)) {
+    const bool png = png_has_signature(sig, got), jpeg = jpeg_has_signature(sig, got);
+    if (png || jpeg) {
       std::vector<unsigned char> file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
       image out;
       std::string why;
-      if (!png_decode_rgba8(file, out.m_width, out.m_height, out.m_pixels, why)) fail(path, why.c_str());
+      const bool ok = png ? png_decode_rgba8(file, out.m_width, out.m_height, out.m_pixels, why)
+                          : jpeg_decode_rgba8(file, out.m_width, out.m_height, out.m_pixels, why);
+      if (!ok) fail(path, why.c_str());
       return out;
     }
   }

@@ -3,8 +3,8 @@
 // The reference decodes through stb_image with `stbi_hdr_to_ldr_gamma(2.2f)`, scale 1, 4 channels
 // (app/hdre_loader.cpp:7-24), i.e. per colour channel  byte = clamp(pow(x, 1/2.2) * 255 + 0.5), alpha 255.
 // This reader implements the Radiance format itself (flat and run-length scanlines, `-Y h +X w`) and that
-// conversion.  PNG files (recognised by signature, as stb does) go through png_reader.hpp; JPEG and the other
-// containers stb accepts are not handled.
+// conversion.  PNG and JPEG files (recognised by signature, as stb does) go through png_reader.hpp and
+// jpeg_reader.hpp; the other containers stb accepts (BMP, TGA, GIF, PSD, PIC, PNM) are not handled.
 #pragma once
 
 #include <string>

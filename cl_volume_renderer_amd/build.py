@@ -27,7 +27,7 @@ FLAGS = [
 
 HOST_LIB = os.path.join(HERE, "libclvr_host.so")
 APP = os.path.join(HERE, "app")
-HOST_SOURCES = ["renderer.cpp", "reference_volume.cpp", "signed_distance_field.cpp", "nrrd_loader.cpp", "hdre_loader.cpp", "png_reader.cpp", "tf_part.cpp", "host_c_api.cpp"]
+HOST_SOURCES = ["renderer.cpp", "reference_volume.cpp", "signed_distance_field.cpp", "nrrd_loader.cpp", "hdre_loader.cpp", "png_reader.cpp", "jpeg_reader.cpp", "tf_part.cpp", "host_c_api.cpp"]
 HOST_PROGRAMS = {"sdf_test": "sdf_test_main.cpp", "sdf_benchmark": "sdf_benchmark_main.cpp", "clvr_headless": "headless_main.cpp"}
 CXX = os.environ.get("CXX", "g++")
 

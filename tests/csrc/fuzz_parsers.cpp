@@ -14,6 +14,7 @@
 #include <unistd.h>
 
 #include "../../cl_volume_renderer_amd/app/hdre_loader.hpp"
+#include "../../cl_volume_renderer_amd/app/jpeg_reader.hpp"
 #include "../../cl_volume_renderer_amd/app/nrrd_loader.hpp"
 #include "../../cl_volume_renderer_amd/app/png_reader.hpp"
 #include "../../include/clwh.h"
@@ -91,7 +92,7 @@ int fuzz_loader(const std::string &kind, long iters, const std::vector<std::vect
   return 0;
 }
 
-// usage: fuzz_parsers <iterations> png|tf <file>...   |   fuzz_parsers <iterations> nrrd|hdr <scratch file> <file>...
+// usage: fuzz_parsers <iterations> png|jpg|tf <file>...   |   fuzz_parsers <iterations> nrrd|hdr <scratch file> <file>...
 int main(int argc, char **argv) {
   if (argc < 4) return 2;
   const long iters = std::atol(argv[1]);
@@ -102,14 +103,30 @@ int main(int argc, char **argv) {
     for (int i = 4; i < argc; ++i) seeds.push_back(read_file(argv[i]));
     return fuzz_loader(kind, iters, seeds, argv[3]);
   }
-  const bool png = kind == "png";
+  const bool png = kind == "png", jpg = kind == "jpg";
   std::vector<std::vector<unsigned char>> seeds;
   for (int i = 3; i < argc; ++i) seeds.push_back(read_file(argv[i]));
   long accepted = 0;
   for (long it = 0; it < iters; ++it) {
     std::vector<unsigned char> b = seeds[rnd() % seeds.size()];
     if (it >= (long)seeds.size()) mutate(b);  // the first rounds run the unmodified seeds
-    if (png) {
+    if (jpg) {
+      unsigned w = 0, h = 0;
+      std::vector<unsigned char> rgba;
+      std::string err;
+      // keep decoded sizes bounded: find SOF and look at its dimensions
+      bool huge = false;
+      for (size_t i = 0; i + 9 < b.size(); ++i)
+        if (b[i] == 0xFF && (b[i + 1] == 0xC0 || b[i + 1] == 0xC1 || b[i + 1] == 0xC2)) {
+          const uint64_t hh = ((uint64_t)b[i + 5] << 8) | b[i + 6], ww = ((uint64_t)b[i + 7] << 8) | b[i + 8];
+          if (ww * hh > (1u << 20)) huge = true;
+        }
+      if (huge) continue;
+      if (jpeg_decode_rgba8(b, w, h, rgba, err)) {
+        if (rgba.size() != (size_t)w * h * 4) { std::fprintf(stderr, "size mismatch\n"); return 1; }
+        ++accepted;
+      }
+    } else if (png) {
       // keep decoded sizes bounded: a mutated IHDR may ask for gigabytes, which is legal but not what is tested here
       if (b.size() >= 24) {
         const uint64_t w = ((uint64_t)b[16] << 24) | (b[17] << 16) | (b[18] << 8) | b[19];

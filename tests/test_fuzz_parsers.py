@@ -19,6 +19,7 @@ def fuzzer(tmp_path_factory):
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
                            os.path.join(ROOT, "tests", "csrc", "fuzz_parsers.cpp"),
                            os.path.join(ROOT, "cl_volume_renderer_amd", "app", "png_reader.cpp"),
+                           os.path.join(ROOT, "cl_volume_renderer_amd", "app", "jpeg_reader.cpp"),
                            os.path.join(ROOT, "cl_volume_renderer_amd", "app", "hdre_loader.cpp"),
                            os.path.join(ROOT, "cl_volume_renderer_amd", "app", "nrrd_loader.cpp"),
                            os.path.join(ROOT, "cl_volume_renderer_amd", "csrc", "tf_parse.cpp"),
@@ -62,6 +63,24 @@ def test_png_reader_survives_mutated_files(fuzzer, tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     accepted = int(out.stdout.split(",")[1].split()[0])
     assert accepted >= len(paths)  # the unmodified seeds decode
+
+
+def test_jpeg_reader_survives_mutated_files(fuzzer, tmp_path):
+    from tests.jpeg_writer import Encoder, quant_table
+
+    rng = np.random.default_rng(5)
+    paths = []
+    for k, (samp, prog, rst) in enumerate([([(1, 1)], False, 0), ([(2, 2), (1, 1), (1, 1)], False, 3), ([(2, 1), (1, 1), (1, 1)], True, 0),
+                                           ([(1, 1)] * 4, False, 0), ([(2, 2), (1, 1), (1, 1)], True, 2)]):
+        planes = [np.clip(rng.normal(128, 50, (21, 27)), 0, 255).astype(np.uint8) for _ in samp]
+        enc = Encoder(planes, samp, [quant_table(0.8), quant_table(1.5)], [0] + [1] * (len(samp) - 1), progressive=prog,
+                      restart=rst, style=k % 2)
+        p = str(tmp_path / ("s%d.jpg" % k))
+        open(p, "wb").write(enc.encode_progressive() if prog else enc.encode_baseline())
+        paths.append(p)
+    out = subprocess.run([fuzzer, "40000", "jpg"] + paths, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert int(out.stdout.split(",")[1].split()[0]) >= len(paths)
 
 
 def test_tf_parser_survives_mutated_sources(fuzzer, tmp_path):

@@ -156,3 +156,87 @@ def test_camera_direction_matches_position3d(ref, mine, orc):
         o = (C.c_float * 3)()
         orc.lib().orc_camera_direction(float(a32), float(b32), o)
         assert np.array_equal(np.array(o[:], np.float32), want)
+
+
+def _ref_decode_in_child(path, w, h):
+    """the reference's loader exits the process on a file it rejects, so JPEG files go through it in a child"""
+    code = ("import ctypes as C, numpy as np, sys\n"
+            "L = C.CDLL(%r)\n"
+            "L.ref_env_load.restype = C.c_longlong\n"
+            "L.ref_env_load.argtypes = [C.c_char_p, C.POINTER(C.c_uint), C.c_void_p, C.c_longlong]\n"
+            "out = np.zeros((%d, %d, 4), np.uint8); d = (C.c_uint * 2)()\n"
+            "n = L.ref_env_load(%r.encode(), d, out.ctypes.data, out.nbytes)\n"
+            "assert n == out.nbytes and (d[0], d[1]) == (%d, %d), (n, d[0], d[1])\n"
+            "np.save(%r, out)\n") % (REF_LIB, h, w, path, w, h, path + ".ref.npy")
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, "the reference's decoder rejected the test stream: " + r.stderr[-400:]
+    return np.load(path + ".ref.npy")
+
+
+def _jpeg_scene(w, h, n, seed):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    planes = []
+    for c in range(n):
+        p = 128 + 90 * np.sin(xx / (5.0 + 3 * c) + c) * np.cos(yy / (7.0 - c)) + rng.normal(0, 12, (h, w))
+        p[h // 3: h // 2, w // 4: w // 2] = 30 + 60 * c  # a hard edge
+        planes.append(np.clip(p, 0, 255).astype(np.uint8))
+    return planes
+
+
+JPEG_CASES = [
+    # name, (w, h), sampling per component, progressive, restart, table style, interleaved, extra
+    ("grey", (37, 29), [(1, 1)], False, 0, 0, True, {}),
+    ("444", (40, 24), [(1, 1)] * 3, False, 0, 1, True, {}),
+    ("420", (53, 47), [(2, 2), (1, 1), (1, 1)], False, 0, 1, True, {}),
+    ("422", (61, 18), [(2, 1), (1, 1), (1, 1)], False, 3, 0, True, {}),
+    ("440", (19, 50), [(1, 2), (1, 1), (1, 1)], False, 0, 0, True, {}),
+    ("411", (70, 20), [(4, 1), (1, 1), (1, 1)], False, 2, 1, True, {}),
+    ("420_noninterleaved", (45, 33), [(2, 2), (1, 1), (1, 1)], False, 5, 0, False, {}),
+    ("one_pixel_wide_chroma", (2, 9), [(2, 2), (1, 1), (1, 1)], False, 0, 0, True, {}),
+    ("q16", (24, 24), [(1, 1)] * 3, False, 0, 0, True, {"scale": 8.0}),
+    ("rgb_ids", (30, 22), [(1, 1)] * 3, False, 0, 0, True, {"ids": [ord("R"), ord("G"), ord("B")]}),
+    ("adobe_rgb", (30, 22), [(1, 1)] * 3, False, 0, 0, True, {"adobe": 0}),
+    ("adobe_ycc_with_jfif", (30, 22), [(2, 1), (1, 1), (1, 1)], False, 0, 0, True, {"adobe": 1, "jfif": True}),
+    ("cmyk", (26, 21), [(1, 1)] * 4, False, 0, 0, True, {"adobe": 0}),
+    ("ycck", (26, 21), [(2, 2), (1, 1), (1, 1), (2, 2)], False, 0, 1, True, {"adobe": 2}),
+    ("prog_grey", (37, 29), [(1, 1)], True, 0, 0, True, {}),
+    ("prog_420", (53, 47), [(2, 2), (1, 1), (1, 1)], True, 0, 1, True, {}),
+    ("prog_444_restart", (41, 30), [(1, 1)] * 3, True, 4, 0, True, {}),
+    ("prog_422_flat", (64, 40), [(2, 1), (1, 1), (1, 1)], True, 0, 1, True, {"flat": True}),
+    ("prog_simple_script", (33, 33), [(2, 2), (1, 1), (1, 1)], True, 0, 0, True,
+     {"script": [([0, 1, 2], 0, 0, 0, 0), ([0], 1, 63, 0, 0), ([1], 1, 63, 0, 0), ([2], 1, 63, 0, 0)]}),
+]
+
+
+@pytest.mark.parametrize("case", JPEG_CASES, ids=[c[0] for c in JPEG_CASES])
+def test_jpeg_environment_maps_decode_like_the_reference(ref, mine, tmp_path, case):
+    """JPEG env maps (reference README.md:29) through app/jpeg_reader.cpp vs the reference's stb_image: baseline and
+    progressive streams, every upsampling path, restart intervals, 16-bit quantisation tables, JFIF / Adobe colour
+    handling (RGB, YCbCr, CMYK, YCCK) -- identical RGBA8 bytes."""
+    from tests.jpeg_writer import Encoder, quant_table
+
+    name, (w, h), samp, progressive, restart, style, interleaved, extra = case
+    planes = _jpeg_scene(w, h, len(samp), len(name) + w)
+    if extra.get("flat"):
+        for p in planes:
+            p[:, w // 2:] = p[0, 0]  # long runs of empty blocks: EOB runs
+    scale = extra.get("scale", 0.6)
+    markers = b""
+    if extra.get("jfif"):
+        markers += b"\xff\xe0" + (16).to_bytes(2, "big") + b"JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00"
+    if "adobe" in extra:
+        markers += b"\xff\xee" + (14).to_bytes(2, "big") + b"Adobe\x00\x64\x00\x00\x00\x00" + bytes([extra["adobe"]])
+    enc = Encoder(planes, samp, [quant_table(scale), quant_table(scale * 1.7)], [0] + [1] * (len(samp) - 1),
+                  progressive=progressive, restart=restart, style=style, markers=markers, ids=extra.get("ids"),
+                  script=extra.get("script"))
+    data = enc.encode_progressive() if progressive else enc.encode_baseline(interleaved)
+    path = str(tmp_path / (name + ".jpg"))
+    open(path, "wb").write(data)
+    want = _ref_decode_in_child(path, w, h)
+    out = np.zeros((h, w, 4), np.uint8)
+    d = (C.c_uint * 2)()
+    assert mine.clvr_host_hdr_probe(path.encode(), d, out.ctypes.data, out.nbytes) == out.nbytes
+    assert (d[0], d[1]) == (w, h)
+    assert np.array_equal(out, want), "first difference at %s" % (np.argwhere(out != want)[:3].tolist(),)
+    assert want[..., :3].std() > 5 and (want[..., 3] == 255).all()
