@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void k_commit(const RenderArgs a) {
 constexpr int kFixupDwords = 32;  // one record = 128 B: header[4] bv_before[3] n_pending[1] 2 x {P[3] factor dir[3]}
 
 #ifndef CLVR_BOUNCE_WAVES_PER_SIMD
-#define CLVR_BOUNCE_WAVES_PER_SIMD 6  // measured: 4/5/6/8 waves per SIMD -> 2.47/2.47/2.38/3.07 ms per 16-pass launch (8 spills)
+#define CLVR_BOUNCE_WAVES_PER_SIMD 4  // register budget 128: no spills; measured 4 / 5 / 6 / 7 -> 24.2 / 24.0 / 23.2 / 17.2 Gsamples/s (profiles/r01_tune_occupancy_v7.txt)
 #endif
 template <bool USE_GRAD, int MODE, bool SMALL>
 __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(const RenderArgs a) {
