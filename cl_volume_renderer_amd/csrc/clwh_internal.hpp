@@ -190,7 +190,7 @@ struct clwh_ctx {
   int32_t tune_step_min_lanes = 0;    // 0: chosen per launch (launch_bounce)
   int32_t tune_refill_min_lanes = 0;  // 0: chosen per launch (launch_bounce)
   int32_t tune_literal_gradient = 0;
-  int32_t tune_unit_group = 4, tune_unit_affinity = 0, tune_unit_queues = 8;
+  int32_t tune_unit_group = 1, tune_unit_affinity = 0, tune_unit_queues = 8;
   uint32_t tune_bounce_max_blocks = 2048;
   bool primary_valid = false;
   uint32_t primary_n_hits = 0;
