@@ -81,6 +81,7 @@ struct RenderArgs {
   int32_t refill_min_lanes;  // idle lanes fetch new items once this many are idle (64: only an empty wave refills)
   uint32_t bounce_max_blocks;  // persistent grid size (256-thread blocks)
   int32_t unit_group;          // chunks per queue group (see k_bounce refill)
+  int32_t unit_block_log2;     // 2^n consecutive chunks go to the same queue
   int32_t unit_queues;         // number of unit queues (1..8)
   int32_t unit_affinity;       // 0: the wave's XCD picks its home queue (default); 1: wave number; 2: queue 0 (experiments)
   TfDev tf;
@@ -190,6 +191,7 @@ struct clwh_ctx {
   int32_t tune_step_min_lanes = 0;    // 0: chosen per launch (launch_bounce)
   int32_t tune_refill_min_lanes = 0;  // 0: chosen per launch (launch_bounce)
   int32_t tune_literal_gradient = 0;
+  int32_t tune_unit_block_log2 = 4;
   int32_t tune_unit_group = 1, tune_unit_affinity = 0, tune_unit_queues = 8;
   uint32_t tune_bounce_max_blocks = 2048;
   bool primary_valid = false;

@@ -162,6 +162,7 @@ int clwh_ctx_create_on_stream(int device, void *hip_stream, clwh_ctx **out) {
   if (const char *e = std::getenv("CLWH_TUNE_AFFINITY")) c->tune_unit_affinity = std::atoi(e);
   if (const char *e = std::getenv("CLWH_TUNE_QUEUES")) c->tune_unit_queues = std::max(1, std::min(8, std::atoi(e)));
   if (const char *e = std::getenv("CLWH_TUNE_GROUP")) c->tune_unit_group = std::max(1, std::atoi(e));
+  if (const char *e = std::getenv("CLWH_TUNE_CHUNK_BLOCK_LOG2")) c->tune_unit_block_log2 = std::max(0, std::min(8, std::atoi(e)));
   if (const char *e = std::getenv("CLWH_TUNE_BLOCKS")) c->tune_bounce_max_blocks = (uint32_t)std::max(1, std::atoi(e));
   *out = c;
   return CLWH_OK;
@@ -601,6 +602,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   a.refill_min_lanes = ctx->tune_refill_min_lanes;
   a.bounce_max_blocks = ctx->tune_bounce_max_blocks;
   a.unit_group = ctx->tune_unit_group;
+  a.unit_block_log2 = ctx->tune_unit_block_log2;
   a.unit_affinity = ctx->tune_unit_affinity;
   a.unit_queues = ctx->tune_unit_queues;
 
@@ -648,7 +650,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   }
   a.n_hits = ctx->primary_n_hits;
   // the bounce kernel's queue arithmetic needs ceil(hits / 64) x seeds below 2^24 (64 seeds: 16.7 M hit pixels)
-  if ((uint64_t)((a.n_hits + 63u) >> 6) * (uint64_t)a.n_seeds >= (1ull << 24)) return CLWH_ERR_INVALID_VALUE;
+  if ((uint64_t)(((a.n_hits + 63u) >> 6) + 8u * (1u << ctx->tune_unit_block_log2)) * (uint64_t)a.n_seeds >= (1ull << 24)) return CLWH_ERR_INVALID_VALUE;
 
   // ---- the pass: every (hit, seed) item
   // fix-up records for environment lookups the fast path cannot certify: room for 1/16 of the items;

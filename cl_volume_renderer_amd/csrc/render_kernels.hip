@@ -295,11 +295,15 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
     const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
     if (!exhausted && n_idle >= (uint32_t)a.refill_min_lanes) {
       const uint32_t NQ = (uint32_t)a.unit_queues, S = (uint32_t)a.n_seeds, G = (uint32_t)a.unit_group;
+      const uint32_t KB = (uint32_t)a.unit_block_log2, n_blocks = (n_chunks + (1u << KB) - 1u) >> KB;
       uint32_t base = 0u, count = 0u, q_sel = 0u;
       if (lane == 0u) {
         for (uint32_t tries = 0; tries < NQ && count == 0u; ++tries) {
           const uint32_t q = (home_queue + tries) % NQ;
-          const uint32_t chunks_q = (n_chunks + NQ - 1u - q) / NQ;  // chunks c with c % NQ == q
+          // blocks of 2^unit_block_log2 consecutive chunks are dealt round-robin to the queues (a block past the
+          // last chunk is padding: its items name hits that do not exist and are skipped)
+          const uint32_t blocks_q = (n_blocks + NQ - 1u - q) / NQ;
+          const uint32_t chunks_q = blocks_q << KB;
           if (chunks_q == 0u || ((queue_dry >> q) & 1u)) continue;
           const uint32_t total = chunks_q * S * 64u;
           // every head sits on its own 128-byte line: same-address atomics serialise at one L2 channel
@@ -328,12 +332,13 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
           // `unit_group` units apart (their accumulation atomics do not collide) yet close enough to find
           // each other's voxels still in L2
           // (units per queue stay below 2^24: launch_bounce checks)
-          const uint32_t chunks_q = (n_chunks + NQ - 1u - q_sel) / NQ;  // wave-uniform: scalar
+          const uint32_t chunks_q = ((n_blocks + NQ - 1u - q_sel) / NQ) << KB;  // wave-uniform: scalar
           uint32_t r, c_in;
           const uint32_t g = udivmod24(p, G * S, r);
           const uint32_t in_group = min(G, chunks_q - g * G);  // the last group may be short
           const uint32_t s = udivmod24(r, in_group, c_in), ch = g * G + c_in;
-          const uint32_t h = (q_sel + NQ * ch) * 64u + (item & 63u);
+          const uint32_t chunk = ((q_sel + NQ * (ch >> KB)) << KB) + (ch & ((1u << KB) - 1u));
+          const uint32_t h = chunk * 64u + (item & 63u);
           if (h < a.n_hits) {
             fix = -1;
             npend = 0;
@@ -650,7 +655,7 @@ hipError_t launch_bounce(const RenderArgs &a_in, hipStream_t s) {
   const bool long_launch = waves_needed >= 6u * (uint64_t)blocks * 4u;
   if (a.step_min_lanes <= 0) a.step_min_lanes = long_launch ? 16 : 1;
   if (a.refill_min_lanes <= 0) a.refill_min_lanes = long_launch ? 16 : 64;
-  if ((uint64_t)((a.n_hits + 63u) >> 6) * (uint64_t)a.n_seeds >= (1ull << 24)) return hipErrorInvalidValue;  // udivmod24
+  if ((uint64_t)(((a.n_hits + 63u) >> 6) + 8u * (1u << a.unit_block_log2)) * (uint64_t)a.n_seeds >= (1ull << 24)) return hipErrorInvalidValue;  // udivmod24
   const bool g = a.tf.uses_gradient != 0;
   // fewer than 2^23 bricks (up to ~1600^3): every step byte has a 32-bit offset -> the march's 32-bit addressing
   const bool small = (uint64_t)a.NBX * (uint64_t)a.NBY * (uint64_t)((a.Z + 7) / 8) < (1ull << 23);
