@@ -232,7 +232,11 @@ __global__ __launch_bounds__(256) void k_sdf_front(const SdfFrontArgs a) {
         }
       }
     }
-    __syncthreads();
+    // every wave works on its own s_region slice: only the wave's own LDS writes must be visible to its reads
+    // (LDS operations of one wave execute in order), so a wave-level fence replaces the block barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     int settled = 0;
     bool open_voxels = false;  // does this lane still hold a voxel that may settle in a later layer?
     unsigned face_mask = 0u;  // which faces of the tile this lane's settled voxels lie on: -x +x -y +y -z +z
@@ -292,7 +296,8 @@ __global__ __launch_bounds__(256) void k_sdf_front(const SdfFrontArgs a) {
           a.flags_next[((size_t)nz * a.TY + ny) * a.TX + nx] = 1;
       }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the region is overwritten by the wave's next tile
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
