@@ -379,6 +379,24 @@ def test_env_map_loader_decodes_png(tmp_path, color, depth, interlace):
     assert np.array_equal(out, want)
 
 
+def test_env_map_golden_fixtures():
+    """tests/golden/hostio: files + the RGBA8 the reference's own loader gave for them (made by
+    tests/golden/make_hostio_golden.py from oracle/_ref); usable where the reference tree does not exist"""
+    L = _host()
+    L.clvr_host_hdr_probe.restype = C.c_longlong
+    L.clvr_host_hdr_probe.argtypes = [C.c_char_p, C.POINTER(C.c_uint), C.c_void_p, C.c_longlong]
+    d = os.path.join(ROOT, "tests", "golden", "hostio")
+    names = [n for n in sorted(os.listdir(d)) if not n.endswith(".npy")]
+    assert len(names) >= 4
+    for name in names:
+        want = np.load(os.path.join(d, name + ".rgba.npy"))
+        out = np.zeros_like(want)
+        dims = (C.c_uint * 2)()
+        assert L.clvr_host_hdr_probe(os.path.join(d, name).encode(), dims, out.ctypes.data, out.nbytes) == out.nbytes
+        assert (dims[1], dims[0]) == want.shape[:2]
+        assert np.array_equal(out, want), name
+
+
 @pytest.mark.parametrize("rle,w", [(True, 64), (False, 64), (True, 5), (True, 300)])
 def test_hdre_loader_decodes_radiance_files(tmp_path, rle, w):
     """app/hdre_loader.cpp mirror (CPU only): RGBE decode + gamma-2.2 LDR conversion, checked against the numpy
