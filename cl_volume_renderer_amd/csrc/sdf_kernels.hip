@@ -191,10 +191,14 @@ __global__ __launch_bounds__(256) void k_sdf_base_front(const SdfArgs a, uint8_t
 constexpr unsigned kFrontTilesPerBlock = CLVR_SDF_TILES_PER_BLOCK;  // one wave tests the block's tiles, four waves process the active ones
 constexpr int kRowStride = 16, kSliceStride = 160;  // LDS image of a tile + halo: rows of 16 bytes [x0-4, x0+12)
 
-__global__ __launch_bounds__(256) void k_sdf_front(const SdfFrontArgs a) {
+#ifndef CLVR_SDF_WAVES
+#define CLVR_SDF_WAVES 4
+#endif
+constexpr unsigned kFrontWaves = CLVR_SDF_WAVES;  // waves per block sharing the block's list of active tiles
+__global__ __launch_bounds__(64 * CLVR_SDF_WAVES) void k_sdf_front(const SdfFrontArgs a) {
   __shared__ uint32_t s_list[kFrontTilesPerBlock];
   __shared__ uint32_t s_count;
-  __shared__ __attribute__((aligned(16))) int8_t s_region[4][10 * kSliceStride];
+  __shared__ __attribute__((aligned(16))) int8_t s_region[kFrontWaves][10 * kSliceStride];
   const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
   const uint32_t n_tiles = (uint32_t)a.TX * (uint32_t)a.TY * (uint32_t)a.TZ;
   if (tid == 0) s_count = 0u;
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void k_sdf_front(const SdfFrontArgs a) {
   const int it = a.iteration;
   const bool rows_aligned = (a.X & 3) == 0;
 
-  for (uint32_t k0 = 0; k0 < n_active; k0 += 4u) {
+  for (uint32_t k0 = 0; k0 < n_active; k0 += kFrontWaves) {
     const uint32_t k = k0 + wave;
     const bool have = k < n_active;
     int x0 = 0, y0 = 0, z0 = 0;
@@ -344,7 +348,7 @@ hipError_t launch_sdf_base_front(const SdfArgs &a, uint8_t *flags, int32_t TX, i
 
 hipError_t launch_sdf_front(const SdfFrontArgs &a, hipStream_t s) {
   const uint32_t n_tiles = (uint32_t)a.TX * (uint32_t)a.TY * (uint32_t)a.TZ;
-  hipLaunchKernelGGL(k_sdf_front, dim3((n_tiles + kFrontTilesPerBlock - 1u) / kFrontTilesPerBlock), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_sdf_front, dim3((n_tiles + kFrontTilesPerBlock - 1u) / kFrontTilesPerBlock), dim3(64 * kFrontWaves), 0, s, a);
   return hipGetLastError();
 }
 
