@@ -67,9 +67,10 @@ struct RenderArgs {
   unsigned long long *delta;  // mode 1: this launch's packed sums per hit (see finish_item / k_commit)
   uint32_t *pix_slot;      // tile-major, per pixel: PIX_HIT | hit index, or the miss colour
   HitRec *hits;            // compacted primary hits of this camera
-  uint32_t *counters;      // [0] hits (k_primary), [2] fix-up records, [3] fix-up overflow flag, [32*(q+1)] unit-queue heads, one per 128-B line
+  uint32_t *counters;      // [0] hits (k_primary), [2] fix-up records, [32*(q+1)] unit-queue heads, one per 128-B line
   uint32_t *fixups;        // 128-byte records of samples whose env lookup needs the exact route
   uint32_t fixup_capacity;
+  uint32_t *sticky_flags;  // [0] fix-up overflow (outside the per-launch reset range: survives until the host reads it)
   uint32_t n_hits;         // host copy of counters[0] (valid for k_bounce / k_resolve)
   int64_t *hit_index_out;  // optional, row-major over launch_w x launch_h
   uint32_t *contrib_out;   // optional, row-major uint32[4] (single seed)
@@ -186,6 +187,7 @@ struct clwh_ctx {
   std::string jit_source;
   clvr::TfDev jit_tf{};
   bool fixup_overflow_pending = false;
+  uint32_t *sticky_flags = nullptr;  // [0] fix-up buffer overflow: set by kernels, cleared only when the host has read it
   // measured on MI355X (profiles/r01_tune_*.txt): a wave that runs its 64 samples to completion with
   // steps and events in separate wave-wide phases beats mid-flight refills (12.5 vs 7.6 Gsamples/s)
   int32_t tune_step_min_lanes = 0;    // 0: chosen per launch (launch_bounce)
@@ -202,6 +204,10 @@ struct clwh_ctx {
     int64_t cache_entries;
     int32_t mode;
     uint64_t packed_generation;
+    // miss pixels keep the environment colour of their camera ray: the env map's identity and content are part of the key
+    const void *env;
+    uint64_t env_version;
+    int32_t env_w, env_h;
   } primary_key{};
   uint64_t packed_generation = 0;
   float *bilateral_weights = nullptr;  // 13 x 17 tap weights of the bilateral volume filter (built on first use)

@@ -191,6 +191,7 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
   if (ctx->pix_slot) (void)hipFree(ctx->pix_slot);
   if (ctx->hits) (void)hipFree(ctx->hits);
   if (ctx->render_counters) (void)hipFree(ctx->render_counters);
+  if (ctx->sticky_flags) (void)hipFree(ctx->sticky_flags);
   if (ctx->fixups) (void)hipFree(ctx->fixups);
   if (ctx->delta) (void)hipFree(ctx->delta);
   if (ctx->jit_cls) (void)hipFree(ctx->jit_cls);
@@ -211,12 +212,15 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
 // a render may have overflowed its fix-up buffer (never with sane env-map sizes); the flag is read at
 // the next synchronisation point and reported instead of handing out incomplete results
 static int check_device_flags(clwh_ctx *ctx) {
-  if (!ctx->fixup_overflow_pending || !ctx->render_counters) return CLWH_OK;
+  if (!ctx->fixup_overflow_pending || !ctx->sticky_flags) return CLWH_OK;
   uint32_t flag = 0;
-  HIP_TRY(hipMemcpyAsync(&flag, ctx->render_counters + 3, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(&flag, ctx->sticky_flags, sizeof flag, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   ctx->fixup_overflow_pending = false;
-  return flag ? CLWH_ERR_INTERNAL_OVERFLOW : CLWH_OK;
+  if (!flag) return CLWH_OK;
+  // the flag is sticky on the device (no render resets it): cleared here, once it has been reported
+  HIP_TRY(hipMemsetAsync(ctx->sticky_flags, 0, sizeof(uint32_t), ctx->stream));
+  return CLWH_ERR_INTERNAL_OVERFLOW;
 }
 
 int clwh_ctx_finish(clwh_ctx *ctx) {
@@ -621,6 +625,11 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   rc = grow(ctx, (void **)&ctx->hits, &ctx->hits_bytes, slots * sizeof(HitRec));
   if (rc != CLWH_OK) return rc;
   if (!ctx->render_counters) HIP_TRY(hipMalloc((void **)&ctx->render_counters, clwh_ctx::kRenderCounters * sizeof(uint32_t)));
+  if (!ctx->sticky_flags) {
+    HIP_TRY(hipMalloc((void **)&ctx->sticky_flags, 64));
+    HIP_TRY(hipMemsetAsync(ctx->sticky_flags, 0, 64, ctx->stream));
+  }
+  a.sticky_flags = ctx->sticky_flags;
   a.pix_slot = ctx->pix_slot;
   a.hits = ctx->hits;
   a.counters = ctx->render_counters;
@@ -637,6 +646,9 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   key.cache_entries = a.cache_entries;
   key.mode = a.mode;
   key.packed_generation = ctx->packed_generation;
+  key.env = d->env->dptr;
+  key.env_version = d->env->version;
+  key.env_w = a.env_w; key.env_h = a.env_h;
   if (!ctx->primary_valid || std::memcmp(&key, &ctx->primary_key, sizeof key) != 0 || a.hit_index_out) {
     ctx->primary_valid = false;
     HIP_TRY(hipMemsetAsync(ctx->render_counters, 0, clwh_ctx::kRenderCounters * sizeof(uint32_t), ctx->stream));

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
   __shared__ float div255[256];
   div255[threadIdx.x] = (float)threadIdx.x / 255.0f;
   __syncthreads();
-  // counters: [0] hits, [2] fix-up records, [3] fix-up overflow flag, [32 * (q + 1)] head of unit queue q
+  // counters: [0] hits, [2] fix-up records, [32 * (q + 1)] head of unit queue q (the overflow flag lives in sticky_flags)
   const uint32_t n_chunks = (a.n_hits + 63u) >> 6;
   const unsigned lane = lane_id();
   // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this wave runs on
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
               rec[3] = gx | (gy << 16);
               rec[4] = bv_r; rec[5] = bv_g; rec[6] = bv_b;
             } else {
-              a.counters[3] = 1u;  // reported by the host as an error; the sample is dropped
+              a.sticky_flags[0] = 1u;  // reported by the host as an error; the sample is dropped
               fix = -2;
             }
           }

@@ -69,22 +69,45 @@ def gather_accum(accum, accum_all, world: int):
     return accum_all
 
 
-def reduce_voxel_caches(cache_words, world: int):
-    """Reference-exact voxel-cache mode across ranks (second row): every rank keeps a private
-    world-space cache for its image tiles; the caches are summed once per job.  A cache entry is four u16
-    lanes {r, g, b, count} seen as two 32-bit words, so an all-reduce(SUM) of the words adds lane-wise as long
-    as no lane carries -- which holds exactly while the GLOBAL count of a voxel stays <= 256 (lanes <= 255 x
-    count <= 65280), the same condition under which the single-GPU cache is order-independent (SURVEY facts
-    3, 4).  Beyond the cap every rank has applied the reference's token rule to its own pixels only.
-    `cache_words`: 1-D int32 torch tensor viewing the rank's cache; reduced in place on every rank."""
+def reduce_voxel_caches(cache_words, world: int, chunk_words: int = 1 << 25):
+    """End-of-job sum of the ranks' private world-space caches (second row).  A cache entry is four
+    u16 lanes {r, g, b, count} in two 32-bit words (utility.cl:39-54).  The lanes are widened to int32 before the
+    all-reduce(SUM), so nothing can carry from one lane into its neighbour whatever the global count is, and
+    repacked afterwards:
+      * global count <= 256 (the reference's token cap, ray_marching.cl:28,39): the entry is the exact lane-wise
+        sum -- identical to the single-GPU cache, which is order-independent in that regime (SURVEY facts 3, 4);
+      * global count > 256 (every rank capped only its own pixels): the sums are rescaled to 256 samples
+        (lane * 256 // count, count = 256), i.e. the entry keeps the mean of ALL contributions and fits its u16
+        lanes again.  The reference itself is order-dependent beyond the cap; the mode that applies the token rule
+        to the global count pass by pass is `exchange_pass_contributions` below.
+    `cache_words`: 1-D int32 torch tensor viewing the rank's cache; reduced in place on every rank, chunk by chunk
+    (the widened copy of a chunk is 4 x chunk_words bytes x 2)."""
     if world == 1:
         return cache_words
+    import torch
     import torch.distributed as dist
 
-    if dist.get_backend() == "nccl" or not cache_words.is_cuda:
-        dist.all_reduce(cache_words, op=dist.ReduceOp.SUM)
-    else:  # rehearsal without RCCL (gloo): stage through the host
-        host = cache_words.cpu()
-        dist.all_reduce(host, op=dist.ReduceOp.SUM)
-        cache_words.copy_(host)
+    direct = dist.get_backend() == "nccl" or not cache_words.is_cuda
+    n = cache_words.numel()
+    assert n % 2 == 0
+    chunk_words -= chunk_words % 2
+    for i in range(0, n, chunk_words):
+        w = cache_words[i:i + chunk_words]
+        lanes = torch.stack([w & 0xFFFF, (w >> 16) & 0xFFFF])  # [2][words] int32: low lanes (r, b), high lanes (g, count)
+        if direct:
+            dist.all_reduce(lanes, op=dist.ReduceOp.SUM)
+        else:  # rehearsal without RCCL (gloo): stage through the host
+            host = lanes.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            lanes.copy_(host)
+        lo, hi = lanes[0], lanes[1]
+        count = hi[1::2]
+        over = count > 256
+        if bool(over.any()):
+            c = torch.where(over, count, torch.ones_like(count))
+            lo[0::2] = torch.where(over, lo[0::2] * 256 // c, lo[0::2])  # r   (sums stay below 2^31: 255 x 256 x world)
+            hi[0::2] = torch.where(over, hi[0::2] * 256 // c, hi[0::2])  # g
+            lo[1::2] = torch.where(over, lo[1::2] * 256 // c, lo[1::2])  # b
+            hi[1::2] = torch.clamp(count, max=256)
+        w.copy_(lo | (hi << 16))
     return cache_words

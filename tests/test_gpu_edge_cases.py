@@ -81,3 +81,46 @@ def test_random_rectangle_transfer_functions(gpu_ctx, orc, case):
     pos, d = look_at_centre(vol, [float(rng.integers(-30, -5)), float(rng.integers(20, 60)), float(rng.integers(-30, -5))])
     _parity(orc, gpu_ctx, vol, env, tf, (96, 64), pos, d, scene.glibc_rand(2))
     _parity(orc, gpu_ctx, vol, env, tf, (96, 64), pos, d, [int(rng.integers(0, 2**31 - 1))], mode="image")
+
+
+def test_env_map_swapped_under_a_fixed_camera(gpu_ctx, orc):
+    """the per-camera primary hits keep the env colour of every miss pixel; a different environment
+    map -- a new object, or new content pushed into the same object -- with the same camera, volume and frame
+    size must not resolve the misses with the old map's colours."""
+    vol = scene.phantom(40)
+    tf = scene.tf_default_source()
+    sdf, _, _ = orc.sdf_build(vol, orc.parse_tf(tf))
+    env_a, env_b = scene.env_map(128, 64, seed=1), scene.env_map(128, 64, seed=2)[:, ::-1].copy()
+    assert not np.array_equal(env_a, env_b)
+    pos, d = look_at_centre(vol, [-30, 35, -25])
+    w, h = 96, 64
+    g = GpuScene(gpu_ctx, vol, sdf, env_a, tf, (w, h))
+
+    def want(env, seeds):
+        o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (w, h))
+        for s in seeds:
+            o.render(pos, d, s)
+        o.resolve(pos, d)
+        return o
+
+    g.render(pos, d, 11, debug=False)   # debug outputs would force a primary rebuild
+    oa = want(env_a, [11])
+    assert np.array_equal(g.frame.pull(), oa.frame)
+    misses = oa.frame[..., 3] == 200
+    assert misses.sum() > 500
+    # (1) new content pushed into the SAME image object
+    g.env.push(env_b)
+    gpu_ctx.buffer_reset(g.cache)
+    g.render(pos, d, 11, debug=False)   # debug outputs would force a primary rebuild
+    ob = want(env_b, [11])
+    assert not np.array_equal(oa.frame[misses], ob.frame[misses])
+    assert np.array_equal(g.frame.pull(), ob.frame)
+    assert np.array_equal(g.cache.pull(), ob.cache)
+    # (2) a different image object (renderer::image_set with another env_map)
+    other = gpu_ctx.image_from(env_a, channels=4)
+    old, g.env = g.env, other
+    gpu_ctx.buffer_reset(g.cache)
+    g.render(pos, d, 11, debug=False)   # debug outputs would force a primary rebuild
+    assert np.array_equal(g.frame.pull(), oa.frame)
+    old.release()
+    g.release()

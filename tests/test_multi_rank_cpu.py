@@ -123,3 +123,41 @@ def test_two_rank_voxel_cache_sum_equals_single_rank(orc, tmp_path):
         one.render(pos, d, s)
     assert 0 < one.cache.reshape(-1, 4)[:, 3].max() < 256
     assert np.array_equal(summed, one.cache)
+
+
+def _over_cap_worker(rank, port, out_path):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    # four entries {r, g, b, count}; entry 1 exceeds the cap only globally, entry 2 sits exactly on it
+    e = np.zeros((4, 4), np.uint16)
+    e[0] = (100, 200, 300, 3) if rank == 0 else (7, 8, 9, 1)
+    e[1] = (200 * 255, 200 * 254, 200 * 1, 200) if rank == 0 else (256 * 255, 256 * 3, 256 * 250, 256)
+    e[2] = (128 * 10, 128 * 20, 128 * 30, 128)
+    e[3] = (0, 0, 0, 0)
+    words = torch.from_numpy(e.reshape(-1).view(np.int32).copy())
+    tiles.reduce_voxel_caches(words, WORLD, chunk_words=4)  # two chunks: the chunking is exercised too
+    if rank == 0:
+        np.save(out_path, words.numpy().view(np.uint16).reshape(4, 4))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_voxel_cache_reduce_never_carries_between_lanes(tmp_path):
+    """a raw int32 all-reduce of the packed {r,g,b,count} words lets r carry into g and b into count
+    once the GLOBAL count of a voxel passes 256.  The lanes are widened before the sum; entries over the cap are
+    rescaled to 256 samples."""
+    import torch.multiprocessing as mp
+
+    out = str(tmp_path / "over.npy")
+    mp.spawn(_over_cap_worker, args=(_free_port(), out), nprocs=WORLD, join=True)
+    got = np.load(out).astype(np.int64)
+    assert got[0].tolist() == [107, 208, 309, 4]                      # below the cap: the exact sum
+    total = np.array([200 * 255 + 256 * 255, 200 * 254 + 256 * 3, 200 * 1 + 256 * 250, 456], np.int64)
+    assert got[1].tolist() == [total[0] * 256 // 456, total[1] * 256 // 456, total[2] * 256 // 456, 256]
+    assert got[1, :3].max() <= 255 * 256                              # fits the u16 lanes again
+    assert got[2].tolist() == [256 * 10, 256 * 20, 256 * 30, 256]     # exactly on the cap: still the exact sum
+    assert got[3].tolist() == [0, 0, 0, 0]
