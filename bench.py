@@ -1,27 +1,42 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the volumetric path-tracing hot path on MI355X.
 
-Metric (BASELINE.json): Msamples/s = width x height x spp / seconds, on configs[1]:
-512^3 volume + 4096x2048 env map, 1920x1080, 64 spp (one `render` pass = one sample per pixel,
-reference app/renderer.cpp:131-158), synthetic seeded inputs.
+Metric (BASELINE.json): Msamples/s = width x height x spp / seconds on configs[1]: 512^3 volume +
+4096x2048 env map, 1920x1080 frame, 64 spp (one `render` pass = one sample per pixel, reference
+app/renderer.cpp:131-158), synthetic seeded inputs.
 
-A "step" is one render pass over the whole frame.  `--gpus N` (launched by torch.distributed.run,
-one rank per GPU) shards the SAME frame as interleaved 8x8 image tiles over the ranks (strong
-scaling), each rank accumulating float4 per pixel; the timed region ends with one RCCL all-gather
-of the accumulation tiles and the resolve of the RGBA8 frame.  Inputs are resident in HBM before
-the timed region starts.
+A STEP is one whole frame job of the config: the first frame after a camera move -- primary hits of the
+camera (k_primary), `spp` render passes with fresh glibc-rand() seeds in launches of 64 passes each
+(k_bounce + k_env_fixup + k_commit), [N > 1: ONE RCCL all-gather of the float4 accumulation tiles], resolve
+to the RGBA8 frame.  `--steps K` times exactly K such jobs between barrier + synchronize brackets; because K
+jobs of the headline config take only K x 5.5 ms, the K-step region is repeated until at least
+MIN_TIMED_SECONDS have been measured and the MEDIAN region is reported (every region's time is the max over
+ranks), so the number does not depend on --steps and does not rest on a 2 ms measurement.  Inputs (volume,
+SDF, env map, packed records) are resident in HBM before the clock starts; the frame stays in HBM.
+
+`--gpus N` starts its own N ranks (torch.distributed.run as a child process, before this process touches a
+GPU) unless it already runs under a launcher; the ranks share ONE frame as interleaved 8x8 image tiles
+(strong scaling).  On a box with fewer than N GPUs the same code path is rehearsed on one GPU over gloo.
 
 The JSON line also carries
-  roofline     -- algorithmic bytes per launch (oracle texel counters) / the render
-                  kernel's mean duration measured with HIP events on its stream, vs 8 TB/s HBM;
-  cpu_baseline -- the CPU oracle (a port, not POCL) timed on this host on a bounded sample of the
-                  same workload (rank 0, N=1 only).
+  roofline       the dominant kernel k_bounce against the 8 TB/s HBM peak, counted with the bytes k_bounce
+                 itself performs (oracle counters of the bounce phase only); per-kernel figures and the
+                 SURVEY 8d contract figure (whole path, whole job) beside it;
+  cpu_baseline   the CPU oracle (a port, not POCL) timed on this host on a bounded sample of the same
+                 workload (rank 0, N=1 only);
+  end_to_end     the same jobs including the final blocking frame readback (SURVEY 8d metric ii);
+  drop_in_path   renderer::render_frame x 64 through the C++ host mirror (one pass per launch + frame.pull(),
+                 the reference's own call pattern), and the readback-free / batched variants beside it.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -30,7 +45,17 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MIN_TIMED_SECONDS = 0.5    # the K-step region is repeated until this much has been timed
+MAX_REGIONS = 60
+
+PRESETS = {
+    # BASELINE.json configs[1..4]; the launch shape (64 passes per launch) is the same for every one
+    2: dict(volume=512, width=1920, height=1080, spp=64, tf="default", steps=40, warmup=3),
+    3: dict(volume=512, width=1920, height=1080, spp=256, tf="gradient", steps=10, warmup=1),
+    4: dict(volume=2048, width=3840, height=2160, spp=256, tf="default", steps=3, warmup=1),
+    5: dict(volume=512, width=3840, height=2160, spp=1024, tf="default", steps=3, warmup=1),
+}
 
 
 def log(*a):
@@ -50,82 +75,240 @@ def host_threads():
     return max(1, min(n, int(os.environ.get("BENCH_CPU_THREADS", "16"))))
 
 
-def image_space_bytes(c, samples):
-    """Algorithmic bytes of the image-space pass (DESIGN.md 'Measurement'): SURVEY 8d's formula with
-    the accumulation done per pixel: no token, float4 read-modify-write (32 B) per granted sample,
-    8 B of per-pixel hit scratch instead of the 4 B frame write."""
-    return (c["n_sdf"] + 2 * c["n_vol"] + 4 * c["n_env"] + 32 * c["n_add"] + 8 * samples) / float(samples)
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
-def measured_traffic(world, N, W, H, launches, args):
-    """HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
-    (bench.py cannot run the profiler on itself); only reported for the launch shape that was profiled."""
-    path = os.path.join(ROOT, "profiles", "r01_k_bounce_traffic.json")
-    if world != 1 or (N, W, H, args.steps, launches, args.tf) != (512, 1920, 1080, 64, 1, "default") or not os.path.exists(path):
-        return None
-    t = json.load(open(path))
-    # MI355X_MICROARCH.md, HBM / rocprofv3: on gfx950 FETCH_SIZE tallies the L2's 128-byte fabric read requests at
-    # 64 bytes -- double it; WRITE_SIZE reads exactly.  (The counters are KiB; the json holds bytes.)
-    return round((2.0 * t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]) / 1e9, 3)
-
-
-def voxel_cache_bytes(c, samples):
-    """B = N_sdf + 2 N_vol + 4 N_env + 4 N_tok + 8 N_add + 8 N_read + 4."""
-    return (c["n_sdf"] + 2 * c["n_vol"] + 4 * c["n_env"] + 4 * c["n_tok"] + 8 * c["n_add"]
-            + 8 * c["n_read"] + 4 * samples) / float(samples)
-
-
-def run_voxel_mode(args, ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, seeds, N, W, H, rank, world, dev, barrier,
-                   sdf_build_s, n_layers):
-    """Reference-exact accumulation: every rank renders its image tiles into a private world-space cache
-    (token cap on, one pass per launch as renderer::render_frame does), then ONE all-reduce(SUM) of the
-    caches (tiles.reduce_voxel_caches) and a resolve of the rank's tiles."""
+def spawn_ranks(n):
+    """Start n ranks of this script under torch.distributed.run and exit with the child's code.  Called before
+    anything in this process has touched a GPU (a process that has initialised the GPU must not exec / fork
+    GPU children on this pool); device_count() does not initialise it."""
     import torch
-    import torch.distributed as dist
 
-    from cl_volume_renderer_amd import ffi, tiles
+    env = dict(os.environ)
+    have = torch.cuda.device_count()
+    if have < n:
+        # rehearsal: every rank on GPU 0, collectives over gloo staged through the host (functional check only)
+        env["BENCH_DIST_BACKEND"] = "gloo"
+        env["BENCH_ALL_ON_DEVICE"] = "0"
+        log("[bench] %d GPU(s) visible, %d ranks requested: REHEARSAL on one GPU over gloo" % (have, n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
+
+# ---------------------------------------------------------------------------------------------------------------
+# algorithmic bytes (DESIGN.md 4): texel sizes from SURVEY 8d, counts from the instrumented oracle
+
+
+def bytes_contract_image_space(c):
+    """SURVEY 8d's formula for the whole path, image-space accumulation: per sample
+    N_sdf + 2 N_vol + 4 N_env + 8 N_add (ONE packed 64-bit atomic per granted sample) + 4 (frame write)."""
+    return c["n_sdf"] + 2 * c["n_vol"] + 4 * c["n_env"] + 8 * c["n_add"] + 4 * c["samples"]
+
+
+def bytes_primary(c):
+    """what k_primary performs, once per camera: the primary march, the hit's 6-tap normal, the miss pixels'
+    environment texel, and its per-pixel result (4 B)"""
+    return c["n_sdf_primary"] + 2 * c["n_vol_primary"] + 4 * c["n_env_primary"] + 4 * c["samples"]
+
+
+def bytes_bounce(c):
+    """what k_bounce performs per pass: the distribution rays' marches, their normals, the environment texels of
+    the rays that leave, one 8-byte atomic per granted sample"""
+    return ((c["n_sdf"] - c["n_sdf_primary"]) + 2 * (c["n_vol"] - c["n_vol_primary"])
+            + 4 * (c["n_env"] - c["n_env_primary"]) + 8 * c["n_add"])
+
+
+def measured_traffic(key):
+    """HBM-side bytes per launch of a kernel from the rocprofv3 PMC passes committed under profiles/ (bench.py
+    cannot run the profiler on itself): {workload key: {kernel: {...}}} in profiles/r02_traffic.json."""
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path)).get(key)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# secondary measurements (rank 0, N = 1)
+
+
+def run_dropin(vol, env, tf_source, pos, torch):
+    """The reference application's own call pattern through the C++ host mirror (libclvr_host.so, the classes of
+    app/renderer.hpp over include/clw_*.hpp): ui::run's loop body is `render_frame(state, changed)` = ONE pass per
+    launch in the voxel-cache mode + a blocking frame.pull() (app/renderer.cpp:131-158), at the application's own
+    2048x1024 frame (common_defines.hpp:3-4).  Beside it: the same passes with the display hand-off instead of the
+    readback (renderer::render_frame_device), one pass and eight passes per call."""
+    import ctypes as C
+
+    L = C.CDLL(os.path.join(ROOT, "cl_volume_renderer_amd", "libclvr_host.so"))
+    L.clvr_host_create.restype = C.c_void_p
+    L.clvr_host_destroy.argtypes = [C.c_void_p]
+    L.clvr_host_load.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_uint, C.c_uint]
+    L.clvr_host_flush.argtypes = [C.c_void_p, C.c_char_p]
+    fpp = C.POINTER(C.c_float)
+    L.clvr_host_render_frame.restype = C.c_void_p
+    L.clvr_host_render_frame.argtypes = [C.c_void_p, fpp, fpp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.clvr_host_render_frame_device.argtypes = [C.c_void_p, fpp, fpp, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint, C.c_uint,
+                                                C.c_void_p, C.c_int]
+    Z, Y, X = vol.shape
+    W, H = 2048, 1024
+    h = L.clvr_host_create()
+    L.clvr_host_load(h, vol.ctypes.data, X, Y, Z, env.ctypes.data, env.shape[1], env.shape[0])
+    L.clvr_host_flush(h, tf_source.encode())
+    p = np.asarray(pos, np.float32).copy()
+    look = np.array([0.9, 6.183], np.float32)  # app/ui.cpp:178
+    changed = C.c_int(0)
+    fp = lambda a: a.ctypes.data_as(fpp)
+    out = {"frame": "%dx%d (the application's SCREEN_WIDTH x SCREEN_HEIGHT)" % (W, H), "passes_timed": 64}
+
+    def frames(n, moving):
+        for i in range(n):
+            if moving:
+                p[0] = np.float32(pos[0] + 0.25 * (i % 7))  # a slightly different pose every frame: k_primary runs every frame
+            L.clvr_host_render_frame(h, fp(p), fp(look), W, H, 1, C.byref(changed))
+
+    for label, moving in (("render_frame_still_camera", False), ("render_frame_moving_camera", True)):
+        L.clvr_host_flush(h, tf_source.encode())  # fresh cache (no voxel near the token cap), SDF rebuilt as the app does
+        frames(4, moving)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        frames(64, moving)
+        t = time.perf_counter() - t0  # render_frame ends in a blocking pull: nothing is left in flight
+        out[label] = {"ms_per_frame": round(t * 1e3 / 64, 4), "msamples_per_sec": round(W * H * 64 / t / 1e6, 1),
+                      "includes": "launch + k_bounce (1 pass) + resolve + blocking pull of the 8 MiB frame"}
+
+    display = torch.cuda.Stream()
+    shown = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for label, per_call in (("render_frame_device_1_pass_per_call", 1), ("render_frame_device_8_passes_per_call", 8)):
+        L.clvr_host_flush(h, tf_source.encode())
+        p[0] = np.float32(pos[0])
+        calls = 64 // per_call
+        for _ in range(2):
+            L.clvr_host_render_frame_device(h, fp(p), fp(look), W, H, 1, C.c_void_p(shown.data_ptr()), W, H,
+                                            C.c_void_p(display.cuda_stream), per_call)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            L.clvr_host_render_frame_device(h, fp(p), fp(look), W, H, 1, C.c_void_p(shown.data_ptr()), W, H,
+                                            C.c_void_p(display.cuda_stream), per_call)
+        display.synchronize()
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        out[label] = {"ms_per_pass": round(t * 1e3 / 64, 4), "msamples_per_sec": round(W * H * 64 / t / 1e6, 1),
+                      "includes": "launch + k_bounce + resolve into the display's device buffer, event hand-off; no readback"}
+    L.clvr_host_destroy(h)
+    return out
+
+
+def run_voxel_single(ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, N, W, H, seeds, torch, ffi):
+    """the reference-exact world-space voxel cache (token cap on) through the C ABI, one pass per launch, no readback"""
     n_cache = ffi.cache_len(N, N, N)
-    cache = torch.zeros(n_cache // 2, dtype=torch.int32, device=dev)
+    cache = torch.zeros(n_cache // 2, dtype=torch.int32, device="cuda")
     m_cache = ctx.wrap(cache.data_ptr(), n_cache * 2)
 
-    def one_pass(seed, write_frame):
-        kernel.render(frame=d_frame, volume=d_vol, sdf=d_sdf, env=d_env, buffer_volume=m_cache, cam_pos=pos, cam_dir=cdir,
-                      seed=seed, width=W, height=H, mode=ffi.ACCUM_VOXEL_CACHE, tile_rank=rank, tile_world=world,
-                      write_frame=write_frame)
+    def voxel_pass(seed, wf):
+        kernel.render(frame=d_frame, volume=d_vol, sdf=d_sdf, env=d_env, buffer_volume=m_cache, cam_pos=pos,
+                      cam_dir=cdir, seed=seed, width=W, height=H, mode=ffi.ACCUM_VOXEL_CACHE, write_frame=wf)
 
-    for s in seeds[: args.warmup]:
-        one_pass(s, False)
-    tiles.reduce_voxel_caches(cache, world)  # untimed: channel set-up
+    for s in seeds[:4]:
+        voxel_pass(s, False)
     cache.zero_()
     ctx.invalidate_derived(scene=False, camera=True)
-    torch.cuda.synchronize()
-    barrier()
+    ctx.set_timing(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in seeds[args.warmup:]:
-        one_pass(s, False)
-    tiles.reduce_voxel_caches(cache, world)
+    for i, s in enumerate(seeds):
+        voxel_pass(s, i == len(seeds) - 1)
     torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
+    el = time.perf_counter() - t0
+    timers = ctx.timing_read_all()
+    ctx.set_timing(False)
+    counts = (cache.view(-1, 2)[:, 1] >> 16) & 0xFFFF
+    out = {
+        "what": "world-space voxel cache with the 256-token cap (utility.cl:20-54), fresh cache, %d passes, one pass per "
+                "launch, no host round trip per pass, frame resolved after the last pass" % len(seeds),
+        "value": round(W * H * len(seeds) / el / 1e6, 3),
+        "unit": "Msamples/s",
+        "ms_per_pass": round(el * 1e3 / len(seeds), 4),
+        "k_bounce_ms_per_pass": round(timers["bounce"][0] / max(timers["bounce"][1], 1), 4),
+        "voxels_touched": int((counts > 0).sum().item()),
+        "voxels_at_cap": int((counts >= 256).sum().item()),
+    }
+    del cache
+    return out
+
+
+def run_voxel_multi(args, ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, N, W, H, SPP, K, WU, rank, world, dev,
+                    backend, barrier, max_over_ranks, sdf_build_s, n_layers, torch, dist, ffi, scene, tiles):
+    """--accumulation voxel: the reference's world-space cache across ranks with its 256-token rule applied to the GLOBAL
+    count (tiles.VoxelExchange): every rank renders its image tiles one pass per launch, the ranks all-gather the pass's
+    per-pixel contributions and every rank applies all of them to its replica of the cache in (rank, pixel) order.
+    A step is one frame job of SPP passes ending in the resolve of the whole frame from the replica."""
+    n_cache = ffi.cache_len(N, N, N)
+    n_entries = n_cache // 4
+    cache = torch.zeros(n_cache // 2, dtype=torch.int32, device=dev)
+    m_cache = ctx.wrap(cache.data_ptr(), n_cache * 2)
+    npx = W * H
+    scratch = torch.zeros(ffi.accum_len(W, H, world) * 4, dtype=torch.float32, device=dev)
+    m_scratch = ctx.wrap(scratch.data_ptr(), scratch.numel() * 4)
+    contrib = torch.zeros((npx, 4), dtype=torch.int32, device=dev)
+    m_contrib = ctx.wrap(contrib.data_ptr(), npx * 16)
+    hit = torch.full((npx,), -1, dtype=torch.int64, device=dev)
+    m_hit = ctx.wrap(hit.data_ptr(), npx * 8)
+    seeds = scene.glibc_rand((WU + K + 1) * SPP)
+    xch = tiles.VoxelExchange(cache, world)
+
+    def frame_job(j):
+        cache.zero_()
+        sd = seeds[j * SPP:(j + 1) * SPP]
+        idx = None
+        for i, s in enumerate(sd):
+            kernel.render(frame=None, volume=d_vol, sdf=d_sdf, env=d_env, accum=m_scratch, cam_pos=pos, cam_dir=cdir, seed=s,
+                          width=W, height=H, mode=ffi.ACCUM_IMAGE_SPACE, tile_rank=rank, tile_world=world, write_frame=False,
+                          hit_index=m_hit if i == 0 else None, contrib=m_contrib)
+            if i == 0:  # once per camera: which pixels of this rank hit which voxel
+                idx = torch.nonzero((hit >= 0) & (hit < n_entries)).flatten()
+                xch.set_camera(hit[idx])
+            xch.add_pass(contrib[idx, :3])
+        # every rank holds the whole cache: resolve the whole frame locally (no frame gather)
+        kernel.render(frame=d_frame, volume=d_vol, sdf=d_sdf, env=d_env, buffer_volume=m_cache, cam_pos=pos, cam_dir=cdir, seed=0,
+                      width=W, height=H, mode=ffi.ACCUM_VOXEL_CACHE, resolve_only=True)
+
+    def region(first, k):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(first, first + k):
+            frame_job(j)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    for j in range(WU):
+        region(j, 1)
+    elapsed = max_over_ranks([region(WU, K)])[0]
     counts = (cache.view(-1, 2)[:, 1] >> 16) & 0xFFFF
     if rank == 0:
         print(json.dumps({
-            "metric": "msamples_per_sec", "value": round(W * H * args.steps / elapsed / 1e6, 3), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+            "metric": "msamples_per_sec", "value": round(W * H * SPP * K / elapsed / 1e6, 3), "unit": "Msamples/s",
+            "n_gpus": world, "steps": K, "warmup": WU, "ms_per_step": round(elapsed * 1e3 / K, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[%d]: %d^3 phantom, %dx%d frame, %d spp, reference-exact voxel cache" % (
-                           args.config - 1, N, W, H, args.steps),
-                       "accumulation": "world-space voxel cache per rank (token cap on), one pass per launch, "
-                                       "one all-reduce(SUM) of the caches at the end",
-                       "sdf_build_s": round(sdf_build_s, 4), "sdf_layers": n_layers,
-                       "voxels_touched": int((counts > 0).sum().item()), "max_count": int(counts.max().item())},
+            "config": {"workload": "configs[%d]: %d^3 phantom, %dx%d frame, %d spp per step, reference-exact voxel cache with "
+                                   "the 256-token rule applied to the global count" % (args.config - 1, N, W, H, SPP),
+                       "accumulation": "replicated world-space cache; per pass one all-gather of the hit pixels' contributions "
+                                       "(12 B each) + deterministic capped scatter-add on every rank (tiles.VoxelExchange)",
+                       "sdf_build_s": round(sdf_build_s, 5), "sdf_layers": n_layers,
+                       "voxels_touched": int((counts > 0).sum().item()), "voxels_at_cap": int((counts >= 256).sum().item()),
+                       "max_count": int(counts.max().item())},
         }), flush=True)
     barrier()
     if world > 1:
@@ -135,40 +318,39 @@ def run_voxel_mode(args, ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, s
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed render passes (spp); default from --config")
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--volume", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=None, help="timed frame jobs per region (a job = spp passes of the config)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed frame jobs before the first region")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(PRESETS),
+                    help="BASELINE.json config: 2 = headline (512^3, 1080p, 64 spp, default TF); 3 = 512^3, 1080p, 256 spp, "
+                         "gradient-reading TF (the 7-texel step); 4 = 2048^3, 3840x2160, 256 spp; 5 = 3840x2160, 1024 spp "
+                         "(meant for --gpus 8)")
+    ap.add_argument("--volume", type=int, default=None)
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None, help="render passes per frame job")
     ap.add_argument("--env", type=int, nargs=2, default=[4096, 2048])
     ap.add_argument("--tf", choices=["default", "gradient"], default=None)
-    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 5],
-                    help="BASELINE.json config: 2 = headline (512^3, 1080p, 64 spp, default TF); 3 = 512^3, 1080p, "
-                         "256 spp, gradient-reading TF (the 7-texel step); 5 = 3840x2160, 1024 spp (meant for --gpus 8). "
-                         "Explicit --steps/--width/--height/--tf override the preset")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the baseline sample")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the voxel-cache-mode measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip end_to_end / drop_in_path / reference_exact_mode")
+    ap.add_argument("--single-region", action="store_true", help="time ONE K-step region (profiling runs)")
     ap.add_argument("--accumulation", choices=["image", "voxel"], default="image",
                     help="image: float4 per pixel + one all-gather (the headline); voxel: the reference's world-space "
-                         "cache per rank, one pass per launch, + one all-reduce of the caches (exact below the token cap)")
-    ap.add_argument("--seeds-per-launch", type=int, default=64,
-                    help="render passes fused into one launch of the persistent bounce kernel (1..64)")
+                         "cache, one pass per launch, contributions exchanged pass by pass under the global 256-token rule")
+    ap.add_argument("--seeds-per-launch", type=int, default=64, help="render passes fused into one launch (1..64)")
     args = ap.parse_args()
-    preset = {2: dict(steps=64, width=1920, height=1080, tf="default"),
-              3: dict(steps=256, width=1920, height=1080, tf="gradient"),
-              5: dict(steps=1024, width=3840, height=2160, tf="default")}[args.config]
+    preset = PRESETS[args.config]
     for key, val in preset.items():
-        if getattr(args, key) is None:
+        if getattr(args, key, None) is None:
             setattr(args, key, val)
 
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        spawn_ranks(args.gpus)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = world_env
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs one rank per GPU: launch with python -m torch.distributed.run "
-                             "--nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
 
     import torch
@@ -178,10 +360,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
-    # rehearsal switches (not used by the driver): BENCH_DIST_BACKEND=gloo and BENCH_ALL_ON_DEVICE=0 run the
-    # whole N>1 code path with every rank on one GPU and the gather staged through the host
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
-    if os.environ.get("BENCH_ALL_ON_DEVICE") is not None:
+    rehearsal = os.environ.get("BENCH_ALL_ON_DEVICE") is not None
+    if rehearsal:
         local_rank = int(os.environ["BENCH_ALL_ON_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -191,6 +372,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        log("[bench] rank %d: backend %s, world size seen %d, device cuda:%d" % (rank, dist.get_backend(), dist.get_world_size(), local_rank))
 
     def barrier():
         if world > 1:
@@ -199,13 +381,21 @@ def main():
             else:
                 dist.barrier()
 
-    N, W, H = args.volume, args.width, args.height
+    def max_over_ranks(values):
+        t = torch.tensor(values, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
+
+    N, W, H, SPP = args.volume, args.width, args.height, args.spp
+    K, WU = args.steps, args.warmup
+    S = max(1, min(ffi.MAX_SEEDS, args.seeds_per_launch))
+    threads = host_threads()
     t_setup = time.time()
-    vol = scene.phantom(N)
+    vol = scene.phantom(N) if N < 1024 else scene.phantom_mt(N, threads=threads)
     env = scene.env_map(args.env[0], args.env[1])
     tf_source = scene.tf_default_source() if args.tf == "default" else scene.tf_gradient_source()
     pos, cdir = scene.default_camera(N)
-    seeds = scene.glibc_rand(args.warmup + args.steps)
     if rank == 0:
         log("[bench] scene: phantom(%d) %.1fs" % (N, time.time() - t_setup))
 
@@ -214,13 +404,22 @@ def main():
     d_vol = ctx.image_from(vol)
     d_env = ctx.image_from(env, channels=4)
     d_sdf = ctx.image([N, N, N], 1, np.int8, (N, N, N))
+    ctx.sdf_build(d_vol, tf_source, d_sdf)  # warm (allocations)
     torch.cuda.synchronize()
-    t0 = time.time()
-    n_layers = ctx.sdf_build(d_vol, tf_source, d_sdf)
-    torch.cuda.synchronize()
-    sdf_build_s = time.time() - t0
+    sdf_times = []
+    for _ in range(3 if N <= 512 else 1):
+        t0 = time.perf_counter()
+        n_layers = ctx.sdf_build(d_vol, tf_source, d_sdf)
+        torch.cuda.synchronize()
+        sdf_times.append(time.perf_counter() - t0)
+    sdf_build_s = min(sdf_times)
     d_frame = ctx.image([W, H], 4, np.uint8, (H, W, 4))
     kernel = ctx.kernel("ray_marching.cl", "render", tf_source)
+
+    if args.accumulation == "voxel":
+        run_voxel_multi(args, ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, N, W, H, SPP, K, WU, rank, world, dev,
+                        backend, barrier, max_over_ranks, sdf_build_s, n_layers, torch, dist, ffi, scene, tiles)
+        return
 
     n_acc = ffi.accum_len(W, H, world)
     accum = torch.zeros(n_acc * 4, dtype=torch.float32, device=dev)
@@ -228,79 +427,93 @@ def main():
     m_accum = ctx.wrap(accum.data_ptr(), accum.numel() * 4)
     m_accum_all = ctx.wrap(accum_all.data_ptr(), accum_all.numel() * 4)
 
-    S = max(1, min(ffi.MAX_SEEDS, args.seeds_per_launch))
-    if args.accumulation == "voxel":
-        run_voxel_mode(args, ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, seeds, N, W, H, rank, world, dev,
-                       barrier, sdf_build_s, n_layers)
-        return
+    # seeds: the glibc rand() stream the never-seeded reference draws from, one per pass, continuing over the jobs
+    n_jobs_max = WU + 1 + K * MAX_REGIONS + 64
+    seed_stream = scene.glibc_rand(min(n_jobs_max * SPP, 4_000_000))
 
-    def render_passes(batch):
-        """len(batch) render passes (steps) in one launch of the persistent bounce kernel"""
-        kernel.render(frame=None, volume=d_vol, sdf=d_sdf, env=d_env, accum=m_accum, cam_pos=pos, cam_dir=cdir,
-                      seed=0, seeds=batch, width=W, height=H, mode=ffi.ACCUM_IMAGE_SPACE, tile_rank=rank,
-                      tile_world=world, write_frame=False)
+    def job_seeds(j):
+        a = (j * SPP) % max(1, len(seed_stream) - SPP)
+        return seed_stream[a:a + SPP]
 
-    def batches(seq):
-        return [seq[i:i + S] for i in range(0, len(seq), S)]
+    def frame_job(j, pull=False):
+        """one step: camera -> primary hits -> SPP passes -> (gather) -> RGBA8 frame in HBM"""
+        ctx.invalidate_derived(scene=False, camera=True)  # the first frame after a camera move: k_primary runs
+        accum.zero_()
+        sd = job_seeds(j)
+        for i in range(0, SPP, S):
+            kernel.render(frame=None, volume=d_vol, sdf=d_sdf, env=d_env, accum=m_accum, cam_pos=pos, cam_dir=cdir,
+                          seed=0, seeds=sd[i:i + S], width=W, height=H, mode=ffi.ACCUM_IMAGE_SPACE, tile_rank=rank,
+                          tile_world=world, write_frame=False)
+        tiles.gather_accum(accum, accum_all, world)  # N>1: ONE RCCL all-gather of the float4 tiles over xGMI
+        ctx.accum_resolve(m_accum_all, world, W, H, d_frame, d_env, pos, cdir)
+        if pull:
+            return d_frame.pull()
+        return None
 
-    for b in batches(seeds[: args.warmup]):
-        render_passes(b)
-    # one more untimed launch of the timed launches' shape, so that the context's work buffers (fix-up
-    # records, hit list) have their final size before the clock starts
-    first = seeds[args.warmup: args.warmup + S]
-    if len(first) > args.warmup:
-        render_passes(first)
-    tiles.gather_accum(accum, accum_all, world)  # untimed: RCCL sets its channels up on the first collective of a kind
-    ctx.accum_resolve(m_accum_all, world, W, H, d_frame, d_env, pos, cdir)
-    accum.zero_()
-    # the timed region starts like the first frame after a camera move: the per-camera primary hits are
-    # rebuilt inside it (once); the packed records are flush-time data like the SDF and stay resident
-    ctx.invalidate_derived(scene=False, camera=True)
+    def timed_region(first_job, k, pull=False):
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for j in range(first_job, first_job + k):
+            frame_job(j, pull)
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    job = 0
+    est = []
+    for _ in range(WU + 1):  # warm-up jobs (+1 so the context's work buffers have their final size)
+        est.append(timed_region(job, 1))
+        job += 1
+    est_job = max_over_ranks([min(est)])[0]
+    regions = 1 if args.single_region else max(1, min(MAX_REGIONS, int(math.ceil(MIN_TIMED_SECONDS / max(est_job * K, 1e-6)))))
     ctx.set_timing(True)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for b in batches(seeds[args.warmup:]):
-        render_passes(b)
-    tiles.gather_accum(accum, accum_all, world)  # N>1: ONE RCCL all-gather of the float4 tiles over xGMI
-    ctx.accum_resolve(m_accum_all, world, W, H, d_frame, d_env, pos, cdir)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kern_ms, kern_n = ctx.timing_read()
+    region_s = []
+    for _ in range(regions):
+        region_s.append(timed_region(job, K))
+        job += K
+    timers = ctx.timing_read_all()
     ctx.set_timing(False)
+    region_s = max_over_ranks(region_s)  # every region: the slowest rank's time
+    elapsed = statistics.median(region_s)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    samples_per_job = W * H * SPP
+    value = samples_per_job * K / elapsed / 1e6
+    ranks_seen = [world]
     if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-
-    samples = W * H * args.steps
-    value = samples / elapsed / 1e6
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, dist.get_backend(), dist.get_world_size(), local_rank))
+        ranks_seen = seen
     result = {
         "metric": "msamples_per_sec",
         "value": round(value, 3),
         "unit": "Msamples/s",
         "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(elapsed * 1e3 / args.steps, 4),
+        "steps": K,
+        "warmup": WU,
+        "ms_per_step": round(elapsed * 1e3 / K, 4),
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "configs[%d]: %d^3 int16 phantom + %dx%d RGBA8 env map, %dx%d frame, %d spp "
+            "workload": "configs[%d]: %d^3 int16 phantom + %dx%d RGBA8 env map, %dx%d frame, %d spp per step "
                         "(1 spp per render pass), SDF empty-space skip, %s TF" % (
-                            args.config - 1, N, args.env[0], args.env[1], W, H, args.steps, args.tf),
-            "accumulation": "image-space float4 per pixel, 8x8 tiles interleaved over ranks, "
-                            "one RCCL all-gather + resolve at the end of the timed region",
+                            args.config - 1, N, args.env[0], args.env[1], W, H, SPP, args.tf),
+            "step": "one frame job: k_primary (camera changed) + %d passes in %d launch(es) of <= %d + %s resolve to RGBA8" % (
+                SPP, (SPP + S - 1) // S, S, "RCCL all-gather + " if world > 1 else ""),
+            "accumulation": "image-space float4 per pixel, 8x8 tiles interleaved over ranks",
             "passes_per_launch": S,
-            "sdf_build_s": round(sdf_build_s, 4),
+            "timed": {"regions": regions, "steps_per_region": K, "seconds_median": round(elapsed, 6),
+                      "seconds_min": round(min(region_s), 6), "seconds_max": round(max(region_s), 6),
+                      "seconds_total": round(sum(region_s), 4)},
+            "sdf_build_s": round(sdf_build_s, 5),
             "sdf_layers": n_layers,
+            "ranks": ranks_seen,
+            "rehearsal_on_one_gpu": bool(rehearsal),
         },
     }
 
@@ -308,41 +521,72 @@ def main():
     if rank == 0:
         from oracle import orc_ffi
 
-        threads = host_threads()
         sdf_host = d_sdf.pull()
         osc = orc_ffi.Scene(vol, sdf_host, env, orc_ffi.parse_tf(tf_source), (W, H), mode=orc_ffi.MODE_IMAGE_SPACE,
                             tile_rank=0, tile_world=world, threads=threads)
+        first = job_seeds(WU + 1)
         t0 = time.perf_counter()
-        osc.render(pos, cdir, seeds[args.warmup])
+        osc.render(pos, cdir, first[0])
         t1 = time.perf_counter() - t0
         passes = 1
         if world == 1 and not args.no_cpu_baseline:
-            more = int(max(0, min(15, args.cpu_seconds / max(t1, 1e-3) - 1)))
-            for s in seeds[args.warmup + 1: args.warmup + 1 + more]:
+            more = int(max(0, min(15, SPP - 1, args.cpu_seconds / max(t1, 1e-3) - 1)))
+            for s in first[1:1 + more]:
                 osc.render(pos, cdir, s)
             passes += more
         cpu_s = time.perf_counter() - t0
-        own_px = (W * H) // world  # interleaved tiles: equal shares (1920x1080 tiles divide evenly)
-        counters = osc.counter_dict()
-        bps = image_space_bytes(counters, own_px * passes)
-        spl = args.steps / float(max(kern_n, 1))  # render passes (seeds) per launch
-        per_launch = bps * own_px * spl
-        avg_ms = kern_ms / max(kern_n, 1)
-        achieved = per_launch / (avg_ms * 1e-3) / 1e9
+        own_px = (W * H) // world  # interleaved tiles: equal shares
+        c = osc.counter_dict()
+        c = {k: v / float(passes) for k, v in c.items()}  # per pass
+        c["samples"] = own_px
+        b_ms, b_n = timers["bounce"]
+        p_ms, p_n = timers["primary"]
+        f_ms, f_n = timers["fixup"]
+        r_ms, r_n = timers["resolve"]
+        passes_per_launch = SPP / float((SPP + S - 1) // S)
+        bounce_bytes = bytes_bounce(c) * passes_per_launch          # per launch
+        bounce_avg_ms = b_ms / max(b_n, 1)
+        bounce_gbs = bounce_bytes / (bounce_avg_ms * 1e-3) / 1e9
+        primary_bytes = bytes_primary(c)
+        primary_avg_ms = p_ms / max(p_n, 1)
+        contract_bps = bytes_contract_image_space(c) / float(own_px)
+        contract_gbs = contract_bps * own_px * SPP * K / elapsed / 1e9
+        key = "%d^3 %dx%d %s tf, %d passes per launch, world %d" % (N, W, H, args.tf, int(passes_per_launch), world)
+        traffic = measured_traffic(key) or {}
+        tb = traffic.get("k_bounce")
         result["roofline"] = {
             "bound": "hbm",
             "kernel": "k_bounce",
-            "achieved": round(achieved, 2),
+            "achieved": round(bounce_gbs, 2),
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "traffic_unit": "GB per launch: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, rocprofv3 --pmc, separate passes",
-            "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": measured_traffic(world, N, W, H, kern_n, args),
-            "bytes_per_sample": round(bps, 3),
-            "samples_per_launch": int(own_px * spl),
-            "avg_launch_ms": round(avg_ms, 4),
-            "launches": kern_n,
-            "per_sample": {k: round(v / float(own_px * passes), 4) for k, v in counters.items()},
+            "frac": round(bounce_gbs / HBM_PEAK_GBS, 5),
+            "traffic": round(tb["gb_per_launch"], 3) if tb else None,
+            "traffic_note": (tb or {}).get("note", "GB per launch from rocprofv3 --pmc (profiles/r02_traffic.json); null: this launch shape was not profiled"),
+            "limiter": "dependent 1-byte gathers: L2-miss request rate and VALU issue, not HBM bytes (DESIGN.md 4)",
+            "bytes_per_sample": round(bytes_bounce(c) / float(own_px), 3),
+            "samples_per_launch": int(own_px * passes_per_launch),
+            "algorithmic_gb_per_launch": round(bounce_bytes / 1e9, 4),
+            "avg_launch_ms": round(bounce_avg_ms, 4),
+            "launches": b_n,
+            "what_is_counted": "only what k_bounce executes per pass: N_sdf + 2 N_vol + 4 N_env of the bounce phase + 8 N_add "
+                               "(oracle counters split by phase); the primary march, its normal and the miss pixels' env "
+                               "texels belong to k_primary (once per camera)",
+            "per_kernel": {
+                "k_primary": {"algorithmic_gb_per_launch": round(primary_bytes / 1e9, 4), "avg_launch_ms": round(primary_avg_ms, 4),
+                              "launches": p_n, "achieved": round(primary_bytes / max(primary_avg_ms, 1e-9) / 1e6, 2),
+                              "frac": round(primary_bytes / max(primary_avg_ms, 1e-9) / 1e6 / HBM_PEAK_GBS, 5),
+                              "traffic": round(traffic["k_primary"]["gb_per_launch"], 4) if "k_primary" in traffic else None},
+                "k_env_fixup+k_commit": {"avg_launch_ms": round(f_ms / max(f_n, 1), 4), "launches": f_n},
+                "k_accum_resolve": {"avg_launch_ms": round(r_ms / max(r_n, 1), 4), "launches": r_n,
+                                    "algorithmic_gb_per_launch": round(W * H * 20 / 1e9, 4)},
+            },
+            "contract": {
+                "what": "SURVEY 8d formula over the WHOLE path (primary march attributed to every sample although k_primary "
+                        "performs it once per camera) divided by the whole-job time",
+                "bytes_per_sample": round(contract_bps, 3), "achieved": round(contract_gbs, 2),
+                "frac": round(contract_gbs / HBM_PEAK_GBS, 5)},
+            "per_sample": {k: round(v / float(own_px), 4) for k, v in c.items() if k != "samples"},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = {
@@ -350,44 +594,29 @@ def main():
                 "unit": "Msamples/s",
                 "cores": threads,
                 "kind": "port",
-                "sample": "%d of the %d timed passes (same scene, camera, seeds), OpenMP over image rows; "
-                          "CPU restatement (oracle/), not POCL" % (passes, args.steps),
+                "sample": "%d of the %d passes of one frame job (same scene, camera, seeds), OpenMP over image rows; "
+                          "CPU restatement (oracle/), not POCL" % (passes, SPP),
             }
-        # parity spot check of the measured job itself: the GPU's accumulated float4 for the oracle's passes
-        # is checked in tests; here only report that the frame was produced
         del osc
 
-        # ---- secondary: the reference-exact voxel-cache mode (token cap on), N=1 only
-        if world == 1 and not args.no_secondary:
-            n_cache = ffi.cache_len(N, N, N)
-            cache = torch.zeros(n_cache // 2, dtype=torch.int32, device=dev)
-            m_cache = ctx.wrap(cache.data_ptr(), n_cache * 2)
+    # ---- end to end incl. the final frame readback (SURVEY 8d metric ii); same jobs, frame pulled after each
+    if not args.no_secondary:
+        k2 = max(1, min(K, 10))
+        t = max_over_ranks([timed_region(job, k2, pull=True)])[0]
+        job += k2
+        if rank == 0:
+            result["end_to_end"] = {
+                "what": "the same frame jobs, each followed by the blocking device-to-host copy of the %dx%d RGBA8 frame "
+                        "(clw_image::pull, %.1f MiB)" % (W, H, W * H * 4 / 2 ** 20),
+                "value": round(samples_per_job * k2 / t / 1e6, 3), "unit": "Msamples/s", "steps": k2,
+                "ms_per_step": round(t * 1e3 / k2, 4)}
 
-            def voxel_pass(seed, wf):
-                kernel.render(frame=d_frame, volume=d_vol, sdf=d_sdf, env=d_env, buffer_volume=m_cache, cam_pos=pos,
-                              cam_dir=cdir, seed=seed, width=W, height=H, mode=ffi.ACCUM_VOXEL_CACHE, write_frame=wf)
-
-            for s in seeds[: args.warmup]:
-                voxel_pass(s, False)
-            cache.zero_()
-            ctx.invalidate_derived(scene=False, camera=True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i, s in enumerate(seeds[args.warmup:]):
-                voxel_pass(s, i == args.steps - 1)
-            torch.cuda.synchronize()
-            el2 = time.perf_counter() - t0
-            counts = (cache.view(-1, 2)[:, 1] >> 16) & 0xFFFF
-            result["reference_exact_mode"] = {
-                "what": "world-space voxel cache with the 256-token cap (utility.cl:20-54), fresh cache, same seeds, "
-                        "one pass per launch, frame resolved after the last pass",
-                "value": round(samples / el2 / 1e6, 3),
-                "unit": "Msamples/s",
-                "ms_per_step": round(el2 * 1e3 / args.steps, 4),
-                "voxels_touched": int((counts > 0).sum().item()),
-                "voxels_at_cap": int((counts >= 256).sum().item()),
-            }
-            del cache
+    if rank == 0 and world == 1 and not args.no_secondary and args.config == 2:
+        result["reference_exact_mode"] = run_voxel_single(ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, N, W, H,
+                                                          job_seeds(0), torch, ffi)
+        result["drop_in_path"] = run_dropin(vol, env, tf_source, pos, torch)
+    if rank == 0:
+        ctx.finish()  # raises if a render overflowed its fix-up buffer (results would be incomplete)
         print(json.dumps(result), flush=True)
 
     barrier()

@@ -63,6 +63,22 @@ const void *clvr_host_render_frame(clvr_host *h, const float pos[3], const float
   return p;
 }
 
+// the same iteration with the display hand-off instead of the readback: the frame goes into `device_frame`
+// (frame_w x frame_h RGBA8 device memory of the caller, read on `stream`), `passes` seeds in one launch
+void clvr_host_render_frame_device(clvr_host *h, const float pos[3], const float look[2], int width, int height,
+                                   int cam_changed, void *device_frame, unsigned frame_w, unsigned frame_h, void *stream,
+                                   int passes) {
+  h->state.position = Position3D(pos[0], pos[1], pos[2]);
+  h->state.direction_look[0] = look[0];
+  h->state.direction_look[1] = look[1];
+  h->state.width = width;
+  h->state.height = height;
+  h->state.cam_changed = cam_changed != 0;
+  h->state.path_changed = true;
+  clw_foreign_memory target(h->ctx, device_frame, frame_w, frame_h, stream);
+  h->rend.render_frame_device(h->state, target, passes);
+}
+
 size_t clvr_host_cache_len(clvr_host *h) { return h->rend.voxel_cache().size(); }
 void clvr_host_pull_cache(clvr_host *h, unsigned short *out) {
   auto &c = h->rend.voxel_cache();

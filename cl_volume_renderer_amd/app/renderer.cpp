@@ -64,6 +64,34 @@ void *renderer::render_frame(struct ui_state &state, bool &frame_changed) {
   return &frame[0];
 }
 
+void renderer::render_frame_device(struct ui_state &state, const clw_foreign_memory &target, int passes) {
+  if (!state.cam_changed && !state.path_changed) return;
+  Position3D vec(state.direction_look[0], state.direction_look[1], 0.0, {1.0, 0.0, 0.0});
+  clwh_render_desc d{};
+  d.frame = target.get_device_reference();
+  d.volume = volume->get_reference_volume().get_device_reference();
+  d.sdf = sdf.get_sdf_buffer().get_device_reference();
+  d.env = emap->get_buffer().get_device_reference();
+  d.buffer_volume = buffer_volume.get_device_reference();
+  for (int q = 0; q < 3; ++q) {
+    d.cam_pos[q] = (float)state.position.val[q];
+    d.cam_dir[q] = (float)vec.val[q];
+  }
+  d.width = (uint32_t)state.width;
+  d.height = (uint32_t)state.height;
+  d.accum_mode = CLWH_ACCUM_VOXEL_CACHE;
+  d.tile_world = 1;
+  d.write_frame = 1;
+  passes = std::max(1, std::min(passes, CLWH_MAX_SEEDS));
+  d.n_seeds = passes;
+  for (int k = 0; k < passes; ++k) d.seeds[k] = std::rand();  // the seeds `passes` render_frame calls would have drawn
+  target.acquire();
+  clw_fail_hard_on_error(clwh_render(render_func.get_kernel(), &d));
+  target.release();
+  state.cam_changed = false;
+  state.path_changed = false;
+}
+
 // reference :45-124 -- the 2-D (value, |gradient|) histogram texture of the transfer-function editor:
 // bin the volume, quantise the counts on the host so that small counts stay distinguishable, rank the
 // distinct counts, colour each bin by its rank.  (The reference declares render_tf(width, height) and

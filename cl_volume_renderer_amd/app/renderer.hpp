@@ -4,6 +4,7 @@
 #include <string>
 
 #include <clw_context.hpp>
+#include <clw_foreign_memory.hpp>
 #include <clw_function.hpp>
 #include <clw_image.hpp>
 #include <clw_vector.hpp>
@@ -19,6 +20,14 @@ class renderer : public frame_emitter {
   void *render_frame(struct ui_state &state, bool &frame_changed) override;
   void *render_tf(const unsigned int width, const unsigned int height) override;
   void next_event_code_set(const std::string cl_code) override;
+
+  // not in the reference: the display hand-off without the host readback.  Same pass as
+  // render_frame, but the frame is written into the display's own device memory (`target`: a mapped GL buffer,
+  // see clw_foreign_memory.hpp) and ordered before the display stream's next work by an event -- no pull(), no
+  // 8 MiB over PCIe per frame, no host synchronisation.  `passes` > 1 batches that many std::rand() seeds into
+  // ONE launch while the camera stands still (same cache as `passes` consecutive render_frame calls below the
+  // token cap).
+  void render_frame_device(struct ui_state &state, const clw_foreign_memory &target, int passes = 1);
 
   // not in the reference: read-only access for tests and headless tools
   clw_vector<unsigned short> &voxel_cache() { return buffer_volume; }

@@ -48,8 +48,10 @@ enum : uint32_t { PIX_HIT = 0x80000000u };  // pix_slot: PIX_HIT | hit index, el
 
 struct RenderArgs {
   int32_t X, Y, Z;
-  const uint32_t *packed;  // bricked {value, sdf, class} records (packed_volume.hpp)
+  const uint2 *grec;       // bricked hit records {gx, gy, gz, class} (packed_volume.hpp)
   const uint8_t *stepb;    // bricked per-step bytes (packed_volume.hpp)
+  const int16_t *volume_lin;  // the caller's images (x fastest): literal taps of the rare paths
+  const int8_t *sdf_lin;
   int32_t NBX, NBY;
   const uint32_t *env;     // RGBA8 packed, row-major
   int32_t env_w, env_h;
@@ -71,7 +73,9 @@ struct RenderArgs {
   uint32_t *fixups;        // 128-byte records of samples whose env lookup needs the exact route
   uint32_t fixup_capacity;
   uint32_t *sticky_flags;  // [0] fix-up overflow (outside the per-launch reset range: survives until the host reads it)
-  uint32_t n_hits;         // host copy of counters[0] (valid for k_bounce / k_resolve)
+  uint32_t n_hits;         // host copy of counters[0], or an upper bound of it when n_hits_on_device
+  int32_t n_hits_on_device;  // 1: kernels read the hit count from counters[0] (no host round trip after k_primary)
+  int32_t shading;         // clwh_shading
   int64_t *hit_index_out;  // optional, row-major over launch_w x launch_h
   uint32_t *contrib_out;   // optional, row-major uint32[4] (single seed)
   uint32_t num_tile_slots; // tile slots of this rank
@@ -94,7 +98,7 @@ struct RepackArgs {
   const int8_t *sdf;
   int32_t X, Y, Z;
   int32_t NBX, NBY, NBZ;
-  uint32_t *packed;
+  uint2 *grec;
   uint8_t *stepb;
   const uint8_t *cls_in;   // opaque TF: class byte per voxel (linear), computed by the JIT classifier
   TfDev tf;
@@ -131,6 +135,7 @@ hipError_t launch_bounce(const RenderArgs &a, hipStream_t s);
 hipError_t launch_env_fixup(const RenderArgs &a, hipStream_t s);
 hipError_t launch_commit(const RenderArgs &a, hipStream_t s);
 hipError_t launch_resolve(const RenderArgs &a, hipStream_t s);
+hipError_t launch_ao(const RenderArgs &a, hipStream_t s);
 hipError_t launch_accum_resolve(const RenderArgs &a, const float4 *accum_all, hipStream_t s);
 // ---- fused SDF build: one breadth-first layer over the active 8x8x8 tiles (sdf_kernels.hip)
 struct SdfFrontArgs {
@@ -166,6 +171,7 @@ struct clwh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  hipEvent_t handoff_event = nullptr;  // clwh_ctx_acquire_from / clwh_ctx_release_to
   // per-camera primary hits (derived data, rebuilt when the key below changes)
   uint32_t *pix_slot = nullptr;
   size_t pix_slot_bytes = 0;
@@ -198,11 +204,12 @@ struct clwh_ctx {
   uint32_t tune_bounce_max_blocks = 2048;
   bool primary_valid = false;
   uint32_t primary_n_hits = 0;
+  bool primary_n_hits_known = false;  // false: the count of this camera's hits is only on the device so far
   struct PrimaryKey {
     float cam_pos[3], cam_dir[3];
     int32_t frame_w, frame_h, launch_w, launch_h, tile_rank, tile_world;
     int64_t cache_entries;
-    int32_t mode;
+    int32_t mode, shading;
     uint64_t packed_generation;
     // miss pixels keep the environment colour of their camera ray: the env map's identity and content are part of the key
     const void *env;
@@ -215,7 +222,7 @@ struct clwh_ctx {
   uint8_t *sdf_flags = nullptr;     // 4 x tiles bytes (current / next / being cleared / done)
   size_t sdf_flags_bytes = 0;
   // derived packed volume (single entry, keyed by the source objects' identity + version and the TF)
-  uint32_t *packed = nullptr;
+  uint8_t *packed = nullptr;  // hit records (8 B per voxel of the brick grid), then the step bytes (1 B)
   size_t packed_bytes = 0;
   const void *packed_vol = nullptr, *packed_sdf = nullptr;
   uint64_t packed_vol_ver = 0, packed_sdf_ver = 0;
@@ -226,6 +233,7 @@ struct clwh_ctx {
   // dominant kernel and read back (without a sync per pass) by clwh_ctx_timing_read
   bool timing = false;
   std::vector<hipEvent_t> ev_begin, ev_end;
+  std::vector<int> ev_which;  // enum clwh_timer of each pair
   size_t ev_used = 0;
 };
 

@@ -202,6 +202,7 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
   if (ctx->sdf_counters) (void)hipFree(ctx->sdf_counters);
   if (ctx->sdf_flags) (void)hipFree(ctx->sdf_flags);
   if (ctx->packed) (void)hipFree(ctx->packed);
+  if (ctx->handoff_event) (void)hipEventDestroy(ctx->handoff_event);
   for (hipEvent_t e : ctx->ev_begin) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_end) (void)hipEventDestroy(e);
   if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -229,6 +230,24 @@ int clwh_ctx_finish(clwh_ctx *ctx) {
   return check_device_flags(ctx);
 }
 
+static int order_streams(clwh_ctx *ctx, hipStream_t first, hipStream_t then) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (!ctx->handoff_event) HIP_TRY(hipEventCreateWithFlags(&ctx->handoff_event, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(ctx->handoff_event, first));
+  HIP_TRY(hipStreamWaitEvent(then, ctx->handoff_event, 0));
+  return CLWH_OK;
+}
+
+int clwh_ctx_acquire_from(clwh_ctx *ctx, void *hip_stream) {
+  if (!ctx) return CLWH_ERR_INVALID_VALUE;
+  return order_streams(ctx, (hipStream_t)hip_stream, ctx->stream);
+}
+
+int clwh_ctx_release_to(clwh_ctx *ctx, void *hip_stream) {
+  if (!ctx) return CLWH_ERR_INVALID_VALUE;
+  return order_streams(ctx, ctx->stream, (hipStream_t)hip_stream);
+}
+
 void *clwh_ctx_stream(clwh_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int clwh_ctx_device(clwh_ctx *ctx) { return ctx ? ctx->device : -1; }
 
@@ -239,35 +258,58 @@ int clwh_ctx_set_timing(clwh_ctx *ctx, int enabled) {
   return CLWH_OK;
 }
 
-int clwh_ctx_timing_read(clwh_ctx *ctx, float *total_ms, int32_t *launches) {
-  if (!ctx || !total_ms || !launches) return CLWH_ERR_INVALID_VALUE;
-  *total_ms = 0.0f;
-  *launches = 0;
+int clwh_ctx_timing_read_all(clwh_ctx *ctx, float *ms, int32_t *launches, int32_t n) {
+  if (!ctx || !ms || !launches || n <= 0) return CLWH_ERR_INVALID_VALUE;
+  for (int k = 0; k < n; ++k) { ms[k] = 0.0f; launches[k] = 0; }
   HIP_TRY(hipSetDevice(ctx->device));
   for (size_t i = 0; i < ctx->ev_used; ++i) {
     HIP_TRY(hipEventSynchronize(ctx->ev_end[i]));
-    float ms = 0.0f;
-    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_begin[i], ctx->ev_end[i]));
-    *total_ms += ms;
-    *launches += 1;
+    float t = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&t, ctx->ev_begin[i], ctx->ev_end[i]));
+    const int k = ctx->ev_which[i];
+    if (k >= 0 && k < n) { ms[k] += t; launches[k] += 1; }
   }
   ctx->ev_used = 0;
   return CLWH_OK;
 }
 
-static int timing_slot(clwh_ctx *ctx, hipEvent_t *b, hipEvent_t *e) {
-  if (ctx->ev_used == ctx->ev_begin.size()) {
-    hipEvent_t x, y;
-    HIP_TRY(hipEventCreate(&x));
-    HIP_TRY(hipEventCreate(&y));
-    ctx->ev_begin.push_back(x);
-    ctx->ev_end.push_back(y);
-  }
-  *b = ctx->ev_begin[ctx->ev_used];
-  *e = ctx->ev_end[ctx->ev_used];
-  ctx->ev_used++;
-  return CLWH_OK;
+int clwh_ctx_timing_read(clwh_ctx *ctx, float *total_ms, int32_t *launches) {
+  if (!ctx || !total_ms || !launches) return CLWH_ERR_INVALID_VALUE;
+  float ms[CLWH_TIMER_COUNT];
+  int32_t n[CLWH_TIMER_COUNT];
+  const int rc = clwh_ctx_timing_read_all(ctx, ms, n, CLWH_TIMER_COUNT);
+  *total_ms = ms[CLWH_TIMER_BOUNCE];
+  *launches = n[CLWH_TIMER_BOUNCE];
+  return rc;
 }
+
+// a (begin, end) event pair for one launch of kernel `which`; null events when timing is off
+struct TimedLaunch {
+  clwh_ctx *ctx;
+  hipEvent_t b = nullptr, e = nullptr;
+  int begin(clwh_ctx *c, int which) {
+    ctx = c;
+    if (!c->timing) return CLWH_OK;
+    if (c->ev_used == c->ev_begin.size()) {
+      hipEvent_t x, y;
+      HIP_TRY(hipEventCreate(&x));
+      HIP_TRY(hipEventCreate(&y));
+      c->ev_begin.push_back(x);
+      c->ev_end.push_back(y);
+      c->ev_which.push_back(0);
+    }
+    b = c->ev_begin[c->ev_used];
+    e = c->ev_end[c->ev_used];
+    c->ev_which[c->ev_used] = which;
+    c->ev_used++;
+    HIP_TRY(hipEventRecord(b, c->stream));
+    return CLWH_OK;
+  }
+  int end() {
+    if (e) HIP_TRY(hipEventRecord(e, ctx->stream));
+    return CLWH_OK;
+  }
+};
 
 // ------------------------------------------------------------------------------------------------
 // memory objects
@@ -463,7 +505,7 @@ static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *
   const int X = (int)volume->dims[0], Y = (int)volume->dims[1], Z = (int)volume->dims[2];
   const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 7) / 8;
   const size_t records = (size_t)NBX * NBY * NBZ * 512u;
-  const size_t bytes = records * (sizeof(uint32_t) + 1u);  // records, then the per-step bytes
+  const size_t bytes = records * (sizeof(uint2) + 1u);  // hit records, then the per-step bytes
   if (ctx->packed_valid && ctx->packed_bytes == bytes && ctx->packed_vol == volume->dptr &&
       ctx->packed_sdf == sdf->dptr && ctx->packed_vol_ver == volume->version &&
       ctx->packed_sdf_ver == sdf->version && !std::memcmp(&ctx->packed_tf, &tf, sizeof tf))
@@ -485,11 +527,18 @@ static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *
   r.sdf = (const int8_t *)sdf->dptr;
   r.X = X; r.Y = Y; r.Z = Z;
   r.NBX = NBX; r.NBY = NBY; r.NBZ = NBZ;
-  r.packed = ctx->packed;
-  r.stepb = reinterpret_cast<uint8_t *>(ctx->packed + records);
+  r.grec = reinterpret_cast<uint2 *>(ctx->packed);
+  r.stepb = ctx->packed + records * sizeof(uint2);
   r.cls_in = cls_in;
   r.tf = tf;
-  HIP_TRY(launch_repack(r, ctx->stream));
+  {
+    TimedLaunch t;
+    int trc = t.begin(ctx, CLWH_TIMER_REPACK);
+    if (trc != CLWH_OK) return trc;
+    HIP_TRY(launch_repack(r, ctx->stream));
+    trc = t.end();
+    if (trc != CLWH_OK) return trc;
+  }
   ctx->packed_vol = volume->dptr;
   ctx->packed_sdf = sdf->dptr;
   ctx->packed_vol_ver = volume->version;
@@ -550,6 +599,8 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   if (d->tile_rank < 0 || d->tile_rank >= world) return CLWH_ERR_INVALID_VALUE;
   if (d->n_seeds < 0 || d->n_seeds > CLWH_MAX_SEEDS) return CLWH_ERR_INVALID_VALUE;
   if (d->n_seeds > 1 && d->contrib) return CLWH_ERR_BAD_ARGS;  // per-pixel contribution output: one seed
+  if (d->shading != CLWH_SHADE_LIGHT && d->shading != CLWH_SHADE_AO) return CLWH_ERR_INVALID_VALUE;
+  if (d->shading == CLWH_SHADE_AO && d->accum_mode != CLWH_ACCUM_VOXEL_CACHE) return CLWH_ERR_BAD_ARGS;  // compute_ao lives in buffer_volume
 
   RenderArgs a;
   std::memset(&a, 0, sizeof a);
@@ -566,10 +617,12 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   describe_frame(a, (int32_t)d->width, (int32_t)d->height, fw, fh, d->tile_rank, world, d->cam_pos, d->cam_dir);
   a.frame = d->frame ? (uint32_t *)d->frame->dptr : nullptr;
   a.mode = d->accum_mode;
+  a.shading = d->shading;
   if (a.mode == CLWH_ACCUM_VOXEL_CACHE) {
     if (!d->buffer_volume || d->buffer_volume->bytes < 8) return CLWH_ERR_BAD_ARGS;
     a.cache = (uint32_t *)d->buffer_volume->dptr;
-    a.cache_entries = (int64_t)(d->buffer_volume->bytes / 8);
+    // compute_light: 4 ushorts per voxel (utility.cl:21); compute_ao: 2 ushorts per voxel (utility.cl:127)
+    a.cache_entries = (int64_t)(d->buffer_volume->bytes / (d->shading == CLWH_SHADE_AO ? 4 : 8));
   } else if (a.mode == CLWH_ACCUM_IMAGE_SPACE) {
     const int64_t need = clwh_accum_len(d->width, d->height, world) * 16;
     if (!d->accum || (int64_t)d->accum->bytes < need) return CLWH_ERR_BAD_ARGS;
@@ -613,10 +666,12 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   HIP_TRY(hipSetDevice(ctx->device));
   int rc = ensure_packed(ctx, d->volume, d->sdf, a.tf, cls_in);
   if (rc != CLWH_OK) return rc;
-  a.packed = ctx->packed;
+  a.grec = reinterpret_cast<const uint2 *>(ctx->packed);
   a.NBX = (a.X + 7) / 8;
   a.NBY = (a.Y + 7) / 8;
-  a.stepb = reinterpret_cast<const uint8_t *>(ctx->packed + (size_t)a.NBX * a.NBY * ((a.Z + 7) / 8) * 512u);
+  a.stepb = ctx->packed + (size_t)a.NBX * a.NBY * ((a.Z + 7) / 8) * 512u * sizeof(uint2);
+  a.volume_lin = (const int16_t *)d->volume->dptr;
+  a.sdf_lin = (const int8_t *)d->sdf->dptr;
 
   // ---- primary hits of this camera: rebuilt only when something they depend on changed
   const size_t slots = (size_t)a.num_tile_slots * 64u;
@@ -645,6 +700,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   key.tile_rank = a.tile_rank; key.tile_world = a.tile_world;
   key.cache_entries = a.cache_entries;
   key.mode = a.mode;
+  key.shading = a.shading;
   key.packed_generation = ctx->packed_generation;
   key.env = d->env->dptr;
   key.env_version = d->env->version;
@@ -652,57 +708,96 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   if (!ctx->primary_valid || std::memcmp(&key, &ctx->primary_key, sizeof key) != 0 || a.hit_index_out) {
     ctx->primary_valid = false;
     HIP_TRY(hipMemsetAsync(ctx->render_counters, 0, clwh_ctx::kRenderCounters * sizeof(uint32_t), ctx->stream));
+    TimedLaunch t;
+    rc = t.begin(ctx, CLWH_TIMER_PRIMARY);
+    if (rc != CLWH_OK) return rc;
     HIP_TRY(launch_primary(a, ctx->stream));
-    uint32_t n_hits = 0;
-    HIP_TRY(hipMemcpyAsync(&n_hits, ctx->render_counters, sizeof n_hits, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // once per camera / scene change: sizes the bounce grid
-    ctx->primary_n_hits = n_hits;
+    rc = t.end();
+    if (rc != CLWH_OK) return rc;
+    ctx->primary_n_hits_known = false;
     ctx->primary_key = key;
     ctx->primary_valid = true;
   }
-  a.n_hits = ctx->primary_n_hits;
+  // The hit count stays on the device for single-pass launches (the reference's call pattern, one pass per
+  // renderer::render_frame): the bounce grid is then sized from the pixel count and the kernels read the count
+  // themselves, so a frame after a camera move costs no host round trip.  Multi-pass launches size their work
+  // buffers and scheduling thresholds from the real count: one 4-byte readback per camera.
+  const bool ao = d->shading == CLWH_SHADE_AO;
+  const bool count_on_device = a.n_seeds == 1 || ao;
+  if (!count_on_device && !ctx->primary_n_hits_known) {
+    uint32_t n_hits = 0;
+    HIP_TRY(hipMemcpyAsync(&n_hits, ctx->render_counters, sizeof n_hits, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->primary_n_hits = n_hits;
+    ctx->primary_n_hits_known = true;
+  }
+  a.n_hits_on_device = count_on_device && !ctx->primary_n_hits_known;
+  a.n_hits = ctx->primary_n_hits_known ? ctx->primary_n_hits : (uint32_t)std::min<size_t>(slots, 0xFFFFFFFFu);  // else: upper bound
   // the bounce kernel's queue arithmetic needs ceil(hits / 64) x seeds below 2^24 (64 seeds: 16.7 M hit pixels)
   if ((uint64_t)(((a.n_hits + 63u) >> 6) + 8u * (1u << ctx->tune_unit_block_log2)) * (uint64_t)a.n_seeds >= (1ull << 24)) return CLWH_ERR_INVALID_VALUE;
 
-  // ---- the pass: every (hit, seed) item
-  // fix-up records for environment lookups the fast path cannot certify: room for 1/16 of the items;
-  // the expected rate is 4e-6 x (0.16 w + 0.32 h) per lookup: 0.5 % at 4096x2048, 4 % at the 32768 limit
-  const size_t fix_cap = std::max<size_t>(((size_t)a.n_hits * (size_t)a.n_seeds) / 16u, 4096u);
-  rc = grow(ctx, (void **)&ctx->fixups, &ctx->fixups_bytes, fix_cap * 128u);
-  if (rc != CLWH_OK) return rc;
-  a.fixups = ctx->fixups;
-  a.fixup_capacity = (uint32_t)std::min<size_t>(ctx->fixups_bytes / 128u, 0x7fffffffu);
-  if (a.mode == CLWH_ACCUM_IMAGE_SPACE) {
-    rc = grow(ctx, (void **)&ctx->delta, &ctx->delta_bytes, std::max<size_t>(a.n_hits, 1) * sizeof(unsigned long long));
-    if (rc != CLWH_OK) return rc;
-    a.delta = ctx->delta;
-    HIP_TRY(hipMemsetAsync(ctx->delta, 0, (size_t)a.n_hits * sizeof(unsigned long long), ctx->stream));
-  }
   HIP_TRY(hipMemsetAsync(ctx->render_counters + 1, 0, (clwh_ctx::kRenderCounters - 1) * sizeof(uint32_t), ctx->stream));
   if (a.contrib_out) HIP_TRY(hipMemsetAsync(a.contrib_out, 0, npx * 16, ctx->stream));  // misses contribute nothing
-  hipEvent_t ev_b = nullptr, ev_e = nullptr;
-  if (ctx->timing) {
-    rc = timing_slot(ctx, &ev_b, &ev_e);
+
+  if (d->resolve_only) {
+    if (!a.frame) return CLWH_ERR_BAD_ARGS;
+  } else if (ao) {
+    // ---- ambient occlusion (compute_ao, ray_marching.cl:104-149): one lane per hit, its passes one after the other
+    TimedLaunch t;
+    rc = t.begin(ctx, CLWH_TIMER_AO);
     if (rc != CLWH_OK) return rc;
-    HIP_TRY(hipEventRecord(ev_b, ctx->stream));
-  }
-  HIP_TRY(launch_bounce(a, ctx->stream));
+    HIP_TRY(launch_ao(a, ctx->stream));
+    rc = t.end();
+    if (rc != CLWH_OK) return rc;
+  } else {
+    // ---- the pass: every (hit, seed) item
+    // fix-up records for environment lookups the fast path cannot certify: room for 1/16 of the items;
+    // the expected rate is 4e-6 x (0.16 w + 0.32 h) per lookup: 0.5 % at 4096x2048, 4 % at the 32768 limit
+    const size_t fix_cap = std::max<size_t>(((size_t)a.n_hits * (size_t)a.n_seeds) / 16u, 4096u);
+    rc = grow(ctx, (void **)&ctx->fixups, &ctx->fixups_bytes, fix_cap * 128u);
+    if (rc != CLWH_OK) return rc;
+    a.fixups = ctx->fixups;
+    a.fixup_capacity = (uint32_t)std::min<size_t>(ctx->fixups_bytes / 128u, 0x7fffffffu);
+    if (a.mode == CLWH_ACCUM_IMAGE_SPACE) {
+      rc = grow(ctx, (void **)&ctx->delta, &ctx->delta_bytes, std::max<size_t>(a.n_hits, 1) * sizeof(unsigned long long));
+      if (rc != CLWH_OK) return rc;
+      a.delta = ctx->delta;
+      HIP_TRY(hipMemsetAsync(ctx->delta, 0, (size_t)a.n_hits * sizeof(unsigned long long), ctx->stream));
+    }
+    TimedLaunch t;
+    rc = t.begin(ctx, CLWH_TIMER_BOUNCE);
+    if (rc != CLWH_OK) return rc;
+    HIP_TRY(launch_bounce(a, ctx->stream));
+    rc = t.end();
+    if (rc != CLWH_OK) return rc;
 #ifdef CLVR_BOUNCE_STATS  // experiment builds only (CLVR_EXTRA_HIPCC_FLAGS=-DCLVR_BOUNCE_STATS): scheduling statistics of the launch
-  {
-    uint32_t h[18];
-    HIP_TRY(hipMemcpyAsync(h, ctx->render_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    std::fprintf(stderr, "[bounce stats] items=%llu step_iters=%u avg_march_lanes=%.2f event_phases=%u avg_event_lanes=%.2f "
-                 "refills=%u avg_refill=%.2f events start/exit/hit/none=%u/%u/%u/%u\n",
-                 (unsigned long long)a.n_hits * (unsigned long long)a.n_seeds, h[8], h[8] ? (double)h[9] / h[8] : 0.0, h[10],
-                 h[10] ? (double)h[11] / h[10] : 0.0, h[12], h[12] ? (double)h[13] / h[12] : 0.0, h[14], h[15], h[16], h[17]);
-  }
+    {
+      uint32_t h[18];
+      HIP_TRY(hipMemcpyAsync(h, ctx->render_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      std::fprintf(stderr, "[bounce stats] items=%llu step_iters=%u avg_march_lanes=%.2f event_phases=%u avg_event_lanes=%.2f "
+                   "refills=%u avg_refill=%.2f events start/exit/hit/none=%u/%u/%u/%u\n",
+                   (unsigned long long)h[0] * (unsigned long long)a.n_seeds, h[8], h[8] ? (double)h[9] / h[8] : 0.0, h[10],
+                   h[10] ? (double)h[11] / h[10] : 0.0, h[12], h[12] ? (double)h[13] / h[12] : 0.0, h[14], h[15], h[16], h[17]);
+    }
 #endif
-  HIP_TRY(launch_env_fixup(a, ctx->stream));
-  HIP_TRY(launch_commit(a, ctx->stream));
-  ctx->fixup_overflow_pending = true;
-  if (ctx->timing) HIP_TRY(hipEventRecord(ev_e, ctx->stream));
-  if (d->write_frame && a.frame) HIP_TRY(launch_resolve(a, ctx->stream));
+    TimedLaunch tf;
+    rc = tf.begin(ctx, CLWH_TIMER_FIXUP);
+    if (rc != CLWH_OK) return rc;
+    HIP_TRY(launch_env_fixup(a, ctx->stream));
+    HIP_TRY(launch_commit(a, ctx->stream));
+    rc = tf.end();
+    if (rc != CLWH_OK) return rc;
+    ctx->fixup_overflow_pending = true;
+  }
+  if ((d->write_frame || d->resolve_only) && a.frame) {
+    TimedLaunch t;
+    rc = t.begin(ctx, CLWH_TIMER_RESOLVE);
+    if (rc != CLWH_OK) return rc;
+    HIP_TRY(launch_resolve(a, ctx->stream));
+    rc = t.end();
+    if (rc != CLWH_OK) return rc;
+  }
   if (d->frame) touch(d->frame);
   return CLWH_OK;
 }
@@ -723,7 +818,14 @@ int clwh_accum_resolve(clwh_ctx *ctx, clwh_mem *accum_all, int32_t tile_world, u
   a.env_w = (int32_t)env->dims[0];
   a.env_h = (int32_t)env->dims[1];
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(launch_accum_resolve(a, (const float4 *)accum_all->dptr, ctx->stream));
+  {
+    TimedLaunch t;
+    int trc = t.begin(ctx, CLWH_TIMER_RESOLVE);
+    if (trc != CLWH_OK) return trc;
+    HIP_TRY(launch_accum_resolve(a, (const float4 *)accum_all->dptr, ctx->stream));
+    trc = t.end();
+    if (trc != CLWH_OK) return trc;
+  }
   touch(frame);
   return CLWH_OK;
 }

@@ -39,41 +39,38 @@ __device__ __forceinline__ bool tf_eval(const TfDev &tf, int value_in, int gradi
 }
 
 // ------------------------------------------------------------------------------------------------
-// utility_filter.cl:2-35: central differences v(p+e_k) - v(p-e_k), no 1/2 factor, border texel = 0;
-// the six taps read packed records, all loads issued before any is consumed
-// Per axis the taps use three texel coordinates -- floor(c - 1), floor(c), floor(c + 1) (the reference adds +-1 in
-// float, which is not always floor(c) +- 1) -- and the record index is separable (packed_volume.hpp), so nine
-// per-axis parts and nine range flags serve all six taps.  An out-of-range coordinate contributes part 0 (a valid
-// address) and masks the tap to the border value 0.
+// utility_filter.cl:2-35: central differences v(p+e_k) - v(p-e_k), no 1/2 factor, border texel = 0.
+// The reference adds +-1 to the float position and samples at floor() of the sum; those six texels are the voxel's
+// own neighbours unless an addition rounds across an integer (p.x = 255.99999 + 1 -> 257.0).  Such positions are
+// detected exactly and take the literal six taps from the caller's image; every other position inside the volume
+// reads the voxel's precomputed differences from its hit record: one 8-byte load, one line.
+__device__ __forceinline__ bool taps_are_voxel_neighbours(f3 p) {
+  return floorf(p.x + 1.0f) == floorf(p.x) + 1.0f && floorf(p.x - 1.0f) == floorf(p.x) - 1.0f &&
+         floorf(p.y + 1.0f) == floorf(p.y) + 1.0f && floorf(p.y - 1.0f) == floorf(p.y) - 1.0f &&
+         floorf(p.z + 1.0f) == floorf(p.z) + 1.0f && floorf(p.z - 1.0f) == floorf(p.z) - 1.0f;
+}
+
+__device__ __forceinline__ f3 gradient_literal(const VolumePacked &v, f3 p) {
+  const int dx = v.value_at(p.x + 1.0f, p.y + 0.0f, p.z + 0.0f) - v.value_at(p.x - 1.0f, p.y - 0.0f, p.z - 0.0f);
+  const int dy = v.value_at(p.x + 0.0f, p.y + 1.0f, p.z + 0.0f) - v.value_at(p.x - 0.0f, p.y - 1.0f, p.z - 0.0f);
+  const int dz = v.value_at(p.x + 0.0f, p.y + 0.0f, p.z + 1.0f) - v.value_at(p.x - 0.0f, p.y - 0.0f, p.z - 1.0f);
+  return f3{(float)dx, (float)dy, (float)dz};
+}
+
+// true when the hit record of floor(p) answers for position p: p inside the volume (false for NaN) and its taps regular
+__device__ __forceinline__ bool hit_record_serves(const VolumePacked &v, f3 p) {
+  const bool inside = p.x >= 0.0f && p.y >= 0.0f && p.z >= 0.0f && p.x < (float)v.X && p.y < (float)v.Y && p.z < (float)v.Z;
+  return inside && taps_are_voxel_neighbours(p);
+}
+
 template <bool SMALL = false>
 __device__ __forceinline__ f3 gradient_nn(const VolumePacked &v, f3 p) {
-  using idx_t = typename VolumePacked::Index<SMALL>::type;
-  const float gx0 = floorf(p.x), gxp = floorf(p.x + 1.0f), gxm = floorf(p.x - 1.0f);
-  const float gy0 = floorf(p.y), gyp = floorf(p.y + 1.0f), gym = floorf(p.y - 1.0f);
-  const float gz0 = floorf(p.z), gzp = floorf(p.z + 1.0f), gzm = floorf(p.z - 1.0f);
-  const float fX = (float)v.X, fY = (float)v.Y, fZ = (float)v.Z;
-  const bool ox0 = gx0 >= 0.0f && gx0 < fX, oxp = gxp >= 0.0f && gxp < fX, oxm = gxm >= 0.0f && gxm < fX;  // false for NaN
-  const bool oy0 = gy0 >= 0.0f && gy0 < fY, oyp = gyp >= 0.0f && gyp < fY, oym = gym >= 0.0f && gym < fY;
-  const bool oz0 = gz0 >= 0.0f && gz0 < fZ, ozp = gzp >= 0.0f && gzp < fZ, ozm = gzm >= 0.0f && gzm < fZ;
-  const idx_t x0 = v.template part_x<SMALL>((unsigned)(int)(ox0 ? gx0 : 0.0f));
-  const idx_t xp = v.template part_x<SMALL>((unsigned)(int)(oxp ? gxp : 0.0f));
-  const idx_t xm = v.template part_x<SMALL>((unsigned)(int)(oxm ? gxm : 0.0f));
-  const idx_t y0 = v.template part_y<SMALL>((unsigned)(int)(oy0 ? gy0 : 0.0f));
-  const idx_t yp = v.template part_y<SMALL>((unsigned)(int)(oyp ? gyp : 0.0f));
-  const idx_t ym = v.template part_y<SMALL>((unsigned)(int)(oym ? gym : 0.0f));
-  const idx_t z0 = v.template part_z<SMALL>((unsigned)(int)(oz0 ? gz0 : 0.0f));
-  const idx_t zp = v.template part_z<SMALL>((unsigned)(int)(ozp ? gzp : 0.0f));
-  const idx_t zm = v.template part_z<SMALL>((unsigned)(int)(ozm ? gzm : 0.0f));
-  const idx_t yz = y0 + z0, xz = x0 + z0, xy = x0 + y0;
-  // all six loads are issued before any is consumed
-  const uint32_t rxp = v.rec[xp + yz], rxm = v.rec[xm + yz];
-  const uint32_t ryp = v.rec[yp + xz], rym = v.rec[ym + xz];
-  const uint32_t rzp = v.rec[zp + xy], rzm = v.rec[zm + xy];
-  const bool byz = oy0 && oz0, bxz = ox0 && oz0, bxy = ox0 && oy0;
-  const int vxp = (oxp && byz) ? VolumePacked::value_of(rxp) : 0, vxm = (oxm && byz) ? VolumePacked::value_of(rxm) : 0;
-  const int vyp = (oyp && bxz) ? VolumePacked::value_of(ryp) : 0, vym = (oym && bxz) ? VolumePacked::value_of(rym) : 0;
-  const int vzp = (ozp && bxy) ? VolumePacked::value_of(rzp) : 0, vzm = (ozm && bxy) ? VolumePacked::value_of(rzm) : 0;
-  return f3{(float)(vxp - vxm), (float)(vyp - vym), (float)(vzp - vzm)};
+  if (hit_record_serves(v, p)) {
+    int gx, gy, gz;
+    VolumePacked::hit_gradient(v.template hit_record<SMALL>(p.x, p.y, p.z), gx, gy, gz);
+    return f3{(float)gx, (float)gy, (float)gz};
+  }
+  return gradient_literal(v, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -128,6 +125,17 @@ __device__ __forceinline__ f3 hemisphere_reflective(uint32_t gx, uint32_t gy, f3
   return normalize3(normal * (1.0f - roughness) + correct_direction * roughness);
 }
 
+// utility_sampling.cl:25-36 get_hemisphere_direction (compute_ao's bounce): no roughness blend
+__device__ __forceinline__ f3 hemisphere_direction(uint32_t gx, uint32_t gy, f3 normal, int seed) {
+  const uint32_t useed = (uint32_t)seed + (gx + 1u) * (gy + 1u);
+  const int rx = (int)hash_u32(useed * 0x182205bdu);
+  const int ry = (int)hash_u32(useed * 0xe8d052f3u);
+  const int rz = (int)hash_u32(useed * 0xf1981dcfu);
+  const f3 direction = f3{(float)((rx % 2048) - 1024), (float)((ry % 2048) - 1024), (float)((rz % 2048) - 1024)};
+  const float decider = dot3(direction, normal);
+  return normalize3(direction * decider);
+}
+
 // ------------------------------------------------------------------------------------------------
 // environment map (utility_environment_map.cl:3-13): equirectangular, normalised coords,
 // clamp-to-edge, nearest
@@ -163,36 +171,53 @@ __device__ __forceinline__ bool exited_volume(const Vol &v, f3 q) {
   return exited_max | exited_min;
 }
 
-// Transfer functions that read `gradient`: the class byte is baked from the gradient at the voxel's
-// INTEGER position.  The reference evaluates the six taps at the ray's float position p, i.e. at texels
-// floor(p +- 1); those are the voxel's own neighbours unless an addition rounds across an integer
-// (p.x = 255.99999 + 1 -> 257.0).  Such positions are detected exactly and take the literal 7-fetch route.
-__device__ __forceinline__ bool taps_are_voxel_neighbours(f3 p) {
-  return floorf(p.x + 1.0f) == floorf(p.x) + 1.0f && floorf(p.x - 1.0f) == floorf(p.x) - 1.0f &&
-         floorf(p.y + 1.0f) == floorf(p.y) + 1.0f && floorf(p.y - 1.0f) == floorf(p.y) - 1.0f &&
-         floorf(p.z + 1.0f) == floorf(p.z) + 1.0f && floorf(p.z - 1.0f) == floorf(p.z) - 1.0f;
-}
+// Transfer functions that read `gradient`: the class byte is baked from the gradient at the voxel's INTEGER position;
+// positions whose taps are not the voxel's neighbours (taps_are_voxel_neighbours above) take the literal 7-fetch route.
 
-// one march step's classification on the packed volume: returns true on a Hit (and updates `color`),
-// otherwise `next_sd` is the SDF value for the next step
-// the colour of a Hit found through the step byte: the voxel's class names the transfer-function rule
+// the colour of a Hit found through the step byte: the voxel's class (in its hit record) names the transfer-function rule
+template <bool SMALL = false>
 __device__ __forceinline__ void hit_color(const VolumePacked &v, const TfDev &tf, f3 pos, uint32_t &color) {
-  const unsigned cls = VolumePacked::class_of(v.fetch_f(pos.x, pos.y, pos.z));
+  const unsigned cls = VolumePacked::hit_class(v.template hit_record<SMALL>(pos.x, pos.y, pos.z));  // a step-byte Hit is inside the volume
   const TfRuleDev &rule = tf.rules[cls - 1u];
   if (rule.flags & TF_WRITES_COLOR) color = rule.color;
 }
 
-// DEFER_COLOR: a Hit found through the step byte returns with `color_pending` set instead of fetching the record
-// for the rule's colour -- the persistent bounce kernel does that in its event phase (hit_color), where it costs one
-// pass per event phase rather than one per march iteration in which any lane happens to hit.
+// what a Hit needs from memory in ONE 8-byte load: the rule colour (when `want_color`, i.e. the Hit was found through the
+// step byte and its colour is still pending) and the gradient for the normal
+template <bool SMALL = false>
+__device__ __forceinline__ f3 hit_gradient_and_color(const VolumePacked &v, const TfDev &tf, f3 pos, bool want_color, uint32_t &color) {
+  const bool regular = hit_record_serves(v, pos);
+  if (regular || want_color) {
+    const uint2 r = v.template hit_record<SMALL>(pos.x, pos.y, pos.z);  // either condition implies pos is inside the volume
+    if (want_color) {
+      const TfRuleDev &rule = tf.rules[VolumePacked::hit_class(r) - 1u];
+      if (rule.flags & TF_WRITES_COLOR) color = rule.color;
+    }
+    if (regular) {
+      int gx, gy, gz;
+      VolumePacked::hit_gradient(r, gx, gy, gz);
+      return f3{(float)gx, (float)gy, (float)gz};
+    }
+  }
+  return gradient_literal(v, pos);
+}
+
+// one march step's classification on the packed volume: returns true on a Hit (and updates `color`), otherwise
+// `next_sd` is the SDF value for the next step.
+// DEFER_COLOR: a Hit found through the step byte returns with `color_pending` set instead of fetching the hit record
+// for the rule's colour -- the persistent bounce kernel does that in its event phase together with the normal's gradient
+// (hit_gradient_and_color), where it costs one pass per event phase rather than one per march iteration in which any
+// lane happens to hit.
 template <bool USE_GRAD, bool SMALL = false, bool DEFER_COLOR = false>
 __device__ __forceinline__ bool classify_step(const VolumePacked &v, const TfDev &tf, f3 pos, uint32_t &color, int &next_sd,
                                               bool *color_pending = nullptr) {
   if (USE_GRAD && !tf.opaque && (tf.literal_gradient_taps || !taps_are_voxel_neighbours(pos))) {
-    const uint32_t r = v.fetch_f(pos.x, pos.y, pos.z);
-    const int gradient = (int)(short)f2i(length3(gradient_nn<SMALL>(v, pos)));
-    next_sd = VolumePacked::sdf_of(r) > 0 ? VolumePacked::sdf_of(r) : 0;
-    return tf_eval(tf, VolumePacked::value_of(r), gradient, color);
+    // the reference's own seven fetches, from the caller's images (utility_ray.cl:126-138)
+    const int value = v.value_at(pos.x, pos.y, pos.z);
+    const int gradient = (int)(short)f2i(length3(gradient_literal(v, pos)));
+    const int sd = v.sdf_at_f(pos.x, pos.y, pos.z);
+    next_sd = sd > 0 ? sd : 0;
+    return tf_eval(tf, value, gradient, color);
   }
   const unsigned q = v.template step_marched<SMALL>(pos.x, pos.y, pos.z);  // both callers have just tested !exited_volume(pos)
   next_sd = (int)(q & 0x7Fu);
@@ -201,7 +226,7 @@ __device__ __forceinline__ bool classify_step(const VolumePacked &v, const TfDev
     *color_pending = true;
     return true;
   }
-  hit_color(v, tf, pos, color);
+  hit_color<SMALL>(v, tf, pos, color);
   return true;
 }
 

@@ -41,7 +41,7 @@ __device__ __forceinline__ uint32_t xcd_contiguous_slot(uint32_t b, uint32_t nbl
 }
 
 __device__ __forceinline__ VolumePacked make_volume(const RenderArgs &a) {
-  return VolumePacked{a.packed, a.stepb, a.X, a.Y, a.Z, a.NBX, a.NBY};
+  return VolumePacked{a.grec, a.stepb, a.volume_lin, a.sdf_lin, a.X, a.Y, a.Z, a.NBX, a.NBY};
 }
 
 // n / d and n % d for n, d < 2^24 through the float reciprocal (a 32-bit integer division is ~35 VALU instructions)
@@ -65,10 +65,10 @@ __device__ __forceinline__ unsigned prefix_count(unsigned long long mask) {
 __device__ __forceinline__ unsigned lane_id() { return prefix_count(~0ull); }
 
 // ------------------------------------------------------------------------------------------------
-// volume + SDF + transfer function -> packed bricked records; one wave writes one 4x4x4 sub-brick
-// (256 contiguous bytes)
+// volume + SDF + transfer function -> bricked step bytes + hit records (packed_volume.hpp); one wave writes one
+// 4x4x4 sub-brick (64 B of step bytes, 512 B of hit records)
 __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
-  const size_t sub_id = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);  // 64 consecutive records of a brick
+  const size_t sub_id = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);  // 64 consecutive voxels of a brick
   const size_t n_sub = (size_t)a.NBX * a.NBY * a.NBZ * 8u;
   if (sub_id >= n_sub) return;
   const size_t brick = sub_id >> 3;
@@ -79,23 +79,24 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
   unsigned ix, iy, iz;
   VolumePacked::inner_coords((unsigned)(sub_id & 7u) * 64u + lane, ix, iy, iz);
   const int x = bx * 8 + (int)ix, y = by * 8 + (int)iy, z = bz * 8 + (int)iz;
-  uint32_t r = 0u;
+  uint2 r = uint2{0u, 0u};
   uint8_t q = 0u;
   if (x < a.X && y < a.Y && z < a.Z) {
     const size_t i = ((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x;
     const int value = a.volume[i];
     const int sd = a.sdf[i];
+    // central differences at the voxel's integer position, border 0 (utility_filter.cl:2-35)
+    auto at = [&](int px, int py, int pz) -> int {
+      if ((unsigned)px >= (unsigned)a.X || (unsigned)py >= (unsigned)a.Y || (unsigned)pz >= (unsigned)a.Z) return 0;
+      return a.volume[((size_t)pz * (size_t)a.Y + (size_t)py) * (size_t)a.X + (size_t)px];
+    };
+    const int dx = at(x + 1, y, z) - at(x - 1, y, z);
+    const int dy = at(x, y + 1, z) - at(x, y - 1, z);
+    const int dz = at(x, y, z + 1) - at(x, y, z - 1);
     int gradient = 0;
     if (a.tf.uses_gradient) {
-      // |central differences| at the voxel's integer position, border 0 (utility_filter.cl:2-35), to short
-      auto at = [&](int px, int py, int pz) -> int {
-        if ((unsigned)px >= (unsigned)a.X || (unsigned)py >= (unsigned)a.Y || (unsigned)pz >= (unsigned)a.Z) return 0;
-        return a.volume[((size_t)pz * (size_t)a.Y + (size_t)py) * (size_t)a.X + (size_t)px];
-      };
-      const float gx = (float)(at(x + 1, y, z) - at(x - 1, y, z));
-      const float gy = (float)(at(x, y + 1, z) - at(x, y - 1, z));
-      const float gz = (float)(at(x, y, z + 1) - at(x, y, z - 1));
-      gradient = (int)(short)f2i(sqrtf((gx * gx + gy * gy) + gz * gz));
+      const float gx = (float)dx, gy = (float)dy, gz = (float)dz;
+      gradient = (int)(short)f2i(sqrtf((gx * gx + gy * gy) + gz * gz));  // |gradient| to short, as at the call (utility_ray.cl:134)
     }
     // class = 1 + index of the first matching rule; a terminal rule (`return (cond);`) ends the evaluation
     unsigned cls = a.cls_in ? a.cls_in[i] : 0u;
@@ -106,10 +107,10 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
       if (m) { cls = (unsigned)k + 1u; break; }
       if (rule.flags & TF_TERMINAL) break;
     }
-    r = ((uint32_t)value & 0xFFFFu) | (((uint32_t)sd & 0xFFu) << 16) | (cls << 24);
+    r = VolumePacked::pack_hit(dx, dy, dz, cls);
     q = (uint8_t)((cls ? 0x80u : 0u) | (uint32_t)(sd > 0 ? sd : 0));
   }
-  a.packed[sub_id * 64u + lane] = r;
+  a.grec[sub_id * 64u + lane] = r;
   a.stepb[sub_id * 64u + lane] = q;
 }
 
@@ -220,7 +221,7 @@ __device__ __forceinline__ void finish_item(const RenderArgs &a, int64_t entry, 
 // fold one launch's per-hit deltas into the float4 accumulation buffer (one lane per hit = per pixel)
 __global__ __launch_bounds__(256) void k_commit(const RenderArgs a) {
   const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-  if (h >= a.n_hits) return;
+  if (h >= (a.n_hits_on_device ? a.counters[0] : a.n_hits)) return;
   const unsigned long long d = a.delta[h];
   if (d == 0ull) return;
   const uint32_t pslot = a.hits[h].pslot;
@@ -252,7 +253,9 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
   div255[threadIdx.x] = (float)threadIdx.x / 255.0f;
   __syncthreads();
   // counters: [0] hits, [2] fix-up records, [32 * (q + 1)] head of unit queue q (the overflow flag lives in sticky_flags)
-  const uint32_t n_chunks = (a.n_hits + 63u) >> 6;
+  // the hit count of this camera: a kernel argument, or still only on the device (single-pass launches, clwh_render)
+  const uint32_t n_hits = a.n_hits_on_device ? a.counters[0] : a.n_hits;
+  const uint32_t n_chunks = (n_hits + 63u) >> 6;
   const unsigned lane = lane_id();
   // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this wave runs on
   unsigned home_queue = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
@@ -339,7 +342,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
           const uint32_t s = udivmod24(r, in_group, c_in), ch = g * G + c_in;
           const uint32_t chunk = ((q_sel + NQ * (ch >> KB)) << KB) + (ch & ((1u << KB) - 1u));
           const uint32_t h = chunk * 64u + (item & 63u);
-          if (h < a.n_hits) {
+          if (h < n_hits) {
             fix = -1;
             npend = 0;
             const uint4 *src = reinterpret_cast<const uint4 *>(&a.hits[h]);
@@ -471,9 +474,9 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
         o += 1;
         start_path = true;
       } else if (ev == EV_HIT || ev == EV_HIT_COLOR_PENDING) {
-        if (ev == EV_HIT_COLOR_PENDING) hit_color(vol, a.tf, ray.origin, color);
-        // ray_marching.cl:63-72: secondary hit -> bounce around the local normal, attenuate
-        bn = -normalize3(gradient_nn<SMALL>(vol, ray.origin));
+        // ray_marching.cl:63-72: secondary hit -> bounce around the local normal, attenuate; the rule colour (still
+        // pending when the Hit came through the step byte) and the gradient arrive in one 8-byte load
+        bn = -normalize3(hit_gradient_and_color<SMALL>(vol, a.tf, ray.origin, ev == EV_HIT_COLOR_PENDING, color));
         bbase = ray;
         bseed = seed + o + i;
         bounce = true;
@@ -570,6 +573,65 @@ __global__ __launch_bounds__(256) void k_env_fixup(const RenderArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// k_ao: compute_ao (ray_marching.cl:104-149) for every primary hit, the launch's passes one after the other in the
+// hit's own lane.  The cache entry is one 32-bit word per voxel, samples | occluded << 16 (the reference's 2-ushort view,
+// utility.cl:123-159).  The reference updates it with a plain read-modify-write that races between pixels sharing a
+// voxel; here the sample is claimed and the occlusion recorded with integer atomics, i.e. the pixels are serialised,
+// which is one legal outcome of that race and independent of the order while the count stays below the cap of 100.
+template <bool USE_GRAD>
+__global__ __launch_bounds__(256) void k_ao(const RenderArgs a) {
+  const uint32_t n_hits = a.n_hits_on_device ? a.counters[0] : a.n_hits;
+  const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= n_hits) return;
+  const VolumePacked vol = make_volume(a);
+  const uint4 *src = reinterpret_cast<const uint4 *>(&a.hits[h]);
+  const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
+  const f3 hit_origin = f3{__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
+  const f3 hit_direction = f3{__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
+  const f3 normal = f3{__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)};
+  const int64_t entry = (int64_t)(((uint64_t)q2.w << 32) | (uint64_t)q2.z);
+  const uint32_t gx = q3.x & 0xFFFFu, gy = q3.x >> 16;
+  if (entry < 0) return;  // outside the allocation: nothing is recorded
+  uint32_t *word = a.cache + entry;
+  for (int s = 0; s < a.n_seeds; ++s) {
+    // `if (buffer_value.x < 100) buffer_value.x += 1`: claim a sample, give it back if the cap was already reached
+    const uint32_t old = atomicAdd(word, 1u);
+    uint32_t granted = 1u, occluded = 0u;
+    if ((old & 0xFFFFu) >= 100u) {
+      atomicSub(word, 1u);
+      granted = 0u;
+    } else {
+      // ray_bounce (utility_ray.cl:100-103), seven unclassified steps, then the occlusion march
+      Ray r{hit_origin + hit_direction, hemisphere_direction(gx, gy, normal, a.seeds[s])};
+      for (int k = 0; k < 7; ++k) {
+        const int sd = (int)(vol.step_i(f2i(r.origin.x), f2i(r.origin.y), f2i(r.origin.z)) & 0x7Fu);
+        r.origin = r.origin + r.direction * cl_max((float)sd, 0.5f);
+      }
+      int ev;
+      uint32_t color = 0u;
+      march_to_next_event<USE_GRAD>(vol, a.tf, r, ev, color);
+      if (ev == EV_HIT) {
+        atomicAdd(word, 0x10000u);
+        occluded = 1u;
+      }
+    }
+    if (a.contrib_out) {
+      uint32_t *q = a.contrib_out + ((size_t)gy * (size_t)a.launch_w + gx) * 4;
+      q[0] = occluded; q[1] = 0u; q[2] = 0u; q[3] = granted;
+    }
+  }
+}
+
+hipError_t launch_ao(const RenderArgs &a, hipStream_t s) {
+  if (a.n_hits == 0) return hipSuccess;
+  const dim3 grid((a.n_hits + 255u) / 256u), block(256);
+  if (a.tf.uses_gradient) hipLaunchKernelGGL(k_ao<true>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(k_ao<false>, grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // resolve: every pixel of this rank reads its accumulator after the whole pass (ray_marching.cl:82-99)
 __global__ __launch_bounds__(64) void k_resolve(const RenderArgs a) {
@@ -585,6 +647,12 @@ __global__ __launch_bounds__(64) void k_resolve(const RenderArgs a) {
   uint32_t out;
   if (!(ps & PIX_HIT)) {
     out = (ps & 0x00FFFFFFu) | (200u << 24);  // miss: environment colour, alpha 200
+  } else if (a.shading == CLWH_SHADE_AO) {
+    // compute_ao's return value (ray_marching.cl:145-148): {v, v, v} with v = (100 - occluded) * 2; shown with alpha 1
+    const HitRec &h = a.hits[ps & ~PIX_HIT];
+    const int64_t e = (int64_t)(((uint64_t)(uint32_t)h.entry_hi << 32) | (uint64_t)(uint32_t)h.entry_lo);
+    const uint32_t v = e < 0 ? 200u : (100u - (a.cache[e] >> 16)) * 2u;
+    out = v | (v << 8) | (v << 16) | (1u << 24);
   } else if (a.mode == CLWH_ACCUM_VOXEL_CACHE) {
     const HitRec &h = a.hits[ps & ~PIX_HIT];
     const int64_t e = (int64_t)(((uint64_t)(uint32_t)h.entry_hi << 32) | (uint64_t)(uint32_t)h.entry_lo);
@@ -652,7 +720,8 @@ hipError_t launch_bounce(const RenderArgs &a_in, hipStream_t s) {
   // A long launch is bound by VALU issue: lanes refill at 16 idle and the march phase ends at 16 marching lanes.
   // Measured crossover on the headline scene: between 4 and 8 passes per launch = about 6 units per wave
   // (profiles/r01_tune_refill_step_thresholds.txt).
-  const bool long_launch = waves_needed >= 6u * (uint64_t)blocks * 4u;
+  // (with the hit count still on the device n_hits is the pixel count, an upper bound: such launches are single-pass)
+  const bool long_launch = !a.n_hits_on_device && waves_needed >= 6u * (uint64_t)blocks * 4u;
   if (a.step_min_lanes <= 0) a.step_min_lanes = long_launch ? 16 : 1;
   if (a.refill_min_lanes <= 0) a.refill_min_lanes = long_launch ? 16 : 64;
   if ((uint64_t)(((a.n_hits + 63u) >> 6) + 8u * (1u << a.unit_block_log2)) * (uint64_t)a.n_seeds >= (1ull << 24)) return hipErrorInvalidValue;  // udivmod24
@@ -677,7 +746,7 @@ hipError_t launch_bounce(const RenderArgs &a_in, hipStream_t s) {
 
 // finish the samples whose environment lookups the fast path could not certify
 hipError_t launch_env_fixup(const RenderArgs &a, hipStream_t s) {
-  if ((uint64_t)a.n_hits * (uint64_t)a.n_seeds == 0) return hipSuccess;
+  if ((uint64_t)a.n_hits * (uint64_t)a.n_seeds == 0) return hipSuccess;  // n_hits is the pixel count when the real one is on the device
   if (a.mode == CLWH_ACCUM_VOXEL_CACHE)
     hipLaunchKernelGGL(k_env_fixup<CLWH_ACCUM_VOXEL_CACHE>, dim3(64), dim3(256), 0, s, a);
   else

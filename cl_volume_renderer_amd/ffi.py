@@ -17,6 +17,8 @@ ELEM_S8, ELEM_S16, ELEM_S32, ELEM_U8, ELEM_U16, ELEM_U32, ELEM_F32 = range(7)
 ARG_MEM, ARG_I32, ARG_U32, ARG_F32, ARG_I64, ARG_U64, ARG_F64 = range(7)
 ACCUM_VOXEL_CACHE, ACCUM_IMAGE_SPACE = 0, 1
 DERIVED_SCENE, DERIVED_CAMERA = 1, 2
+SHADE_LIGHT, SHADE_AO = 0, 1
+TIMERS = ("bounce", "primary", "fixup", "resolve", "repack", "ao")
 MAX_SEEDS = 64
 TF_MAX_RULES = 16
 
@@ -68,6 +70,7 @@ class RenderDesc(C.Structure):
         ("write_frame", C.c_int32),
         ("hit_index", C.c_void_p), ("contrib", C.c_void_p),
         ("n_seeds", C.c_int32), ("seeds", C.c_int32 * 64),
+        ("shading", C.c_int32), ("resolve_only", C.c_int32),
     ]
 
 
@@ -105,8 +108,11 @@ _PROTOTYPES = [
     ("clwh_strerror", C.c_char_p, [C.c_int]),
     ("clwh_last_hip_error", C.c_int, []),
     ("clwh_version", C.c_char_p, []),
+    ("clwh_ctx_acquire_from", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("clwh_ctx_release_to", C.c_int, [C.c_void_p, C.c_void_p]),
     ("clwh_ctx_set_timing", C.c_int, [C.c_void_p, C.c_int]),
     ("clwh_ctx_timing_read", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    ("clwh_ctx_timing_read_all", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int32]),
 ]
 EXPORTED_SYMBOLS = [p[0] for p in _PROTOTYPES]
 
@@ -196,7 +202,7 @@ class Kernel:
 
     def render(self, *, frame, volume, sdf, env, cam_pos, cam_dir, seed, width, height, buffer_volume=None,
                accum=None, mode=ACCUM_VOXEL_CACHE, tile_rank=0, tile_world=1, write_frame=True,
-               hit_index=None, contrib=None, seeds=None):
+               hit_index=None, contrib=None, seeds=None, shading=SHADE_LIGHT, resolve_only=False):
         d = RenderDesc()
         d.frame = frame.h if frame is not None else None
         d.volume, d.sdf, d.env = volume.h, sdf.h, env.h
@@ -211,6 +217,8 @@ class Kernel:
         d.write_frame = 1 if write_frame else 0
         d.hit_index = hit_index.h if hit_index is not None else None
         d.contrib = contrib.h if contrib is not None else None
+        d.shading = shading
+        d.resolve_only = 1 if resolve_only else 0
         if seeds is not None:
             d.n_seeds = len(seeds)
             for i, sd in enumerate(seeds):
@@ -294,6 +302,24 @@ class Context:
         what = (DERIVED_SCENE if scene else 0) | (DERIVED_CAMERA if camera else 0)
         _check(lib().clwh_ctx_invalidate_derived(self.h, what), "clwh_ctx_invalidate_derived")
 
+    def image_wrap(self, device_ptr: int, dims, channels, dtype, shape=None) -> Mem:
+        """adopt device memory somebody else allocated (a graphics-interop mapping, a torch tensor) as an image"""
+        dtype = np.dtype(dtype)
+        d = (C.c_size_t * 3)(*(list(dims) + [1, 1, 1])[:3])
+        h = C.c_void_p()
+        _check(lib().clwh_image_wrap(self.h, C.c_void_p(device_ptr), d, channels, _ELEM_OF_DTYPE[dtype], C.byref(h)),
+               "clwh_image_wrap")
+        n = int(np.prod([max(int(x), 1) for x in list(dims)[:3]])) * channels * dtype.itemsize
+        return Mem(self, h.value, n, dtype, shape)
+
+    def acquire_from(self, stream: int):
+        """the context's later work waits for what is queued on `stream` now (display done with the old frame)"""
+        _check(lib().clwh_ctx_acquire_from(self.h, C.c_void_p(stream)), "clwh_ctx_acquire_from")
+
+    def release_to(self, stream: int):
+        """later work on `stream` waits for what is queued on the context's stream now (frame complete)"""
+        _check(lib().clwh_ctx_release_to(self.h, C.c_void_p(stream)), "clwh_ctx_release_to")
+
     def finish(self):
         _check(lib().clwh_ctx_finish(self.h), "clwh_ctx_finish")
 
@@ -305,6 +331,13 @@ class Context:
         ms, n = C.c_float(0), C.c_int32(0)
         _check(lib().clwh_ctx_timing_read(self.h, C.byref(ms), C.byref(n)), "clwh_ctx_timing_read")
         return float(ms.value), int(n.value)
+
+    def timing_read_all(self):
+        """{kernel: (total ms, launches)} per kernel of the render path since the last read (HIP events)."""
+        n = len(TIMERS)
+        ms, cnt = (C.c_float * n)(), (C.c_int32 * n)()
+        _check(lib().clwh_ctx_timing_read_all(self.h, ms, cnt, n), "clwh_ctx_timing_read_all")
+        return {name: (float(ms[i]), int(cnt[i])) for i, name in enumerate(TIMERS)}
 
     @property
     def stream(self) -> int:

@@ -111,3 +111,98 @@ def reduce_voxel_caches(cache_words, world: int, chunk_words: int = 1 << 25):
             hi[1::2] = torch.clamp(count, max=256)
         w.copy_(lo | (hi << 16))
     return cache_words
+
+
+class VoxelExchange:
+    """The reference's world-space accumulation across ranks WITH its 256-token rule applied to the GLOBAL count
+    (utility.cl:20-31, ray_marching.cl:28,39), pass by pass.
+
+    Every rank keeps an identical replica of the packed voxel cache.  Per camera, the ranks all-gather the cache
+    entry of each of their hit pixels once (`set_camera`); per pass they all-gather only the pixels' contributions
+    (3 x int32 per hit pixel, `add_pass`) and every rank applies ALL of them to its replica with the same
+    deterministic rule: the contributions to one voxel are taken in (rank, pixel) order while the voxel's count is
+    below 256 and dropped afterwards.  That is one legal outcome of the reference's race (which of the competing
+    work-items gets the last tokens is unspecified there), identical on every rank, identical to the single-GPU
+    cache while the global count stays below the cap, and never above the cap.  torch ops only: runs on the GPUs
+    over RCCL and on CPU tensors over gloo (tests/test_multi_rank_cpu.py)."""
+
+    CAP = 256
+
+    def __init__(self, cache_words, world: int):
+        import torch
+
+        self.torch = torch
+        self.words = cache_words        # 1-D int32 tensor, 2 words per entry: r | g << 16, b | count << 16
+        self.world = world
+        self.dev = cache_words.device
+
+    def _all_gather_padded(self, t, n_max):
+        """ranks contribute tensors whose first dimension differs: pad to n_max rows, gather, return the list"""
+        torch = self.torch
+        if self.world == 1:
+            return [t]
+        import torch.distributed as dist
+
+        pad = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        out = torch.empty((self.world * n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        if dist.get_backend() == "nccl" or not t.is_cuda:
+            dist.all_gather_into_tensor(out, pad)
+        else:  # rehearsal without RCCL (gloo): stage through the host
+            host = out.cpu()
+            dist.all_gather_into_tensor(host, pad.cpu())
+            out.copy_(host)
+        return [out[r * n_max:(r + 1) * n_max] for r in range(self.world)]
+
+    def set_camera(self, own_entries):
+        """own_entries: int64 tensor, the cache entry of each of this rank's hit pixels in pixel order (entries
+        outside the cache already removed).  One all-gather per camera."""
+        torch = self.torch
+        n_own = torch.tensor([own_entries.numel()], dtype=torch.int64, device=self.dev)
+        if self.world > 1:
+            import torch.distributed as dist
+
+            sizes = [torch.zeros_like(n_own) for _ in range(self.world)]
+            if dist.get_backend() == "nccl" or not n_own.is_cuda:
+                dist.all_gather(sizes, n_own)
+            else:
+                host = [s.cpu() for s in sizes]
+                dist.all_gather(host, n_own.cpu())
+                sizes = [h.to(self.dev) for h in host]
+            self.sizes = [int(s.item()) for s in sizes]
+        else:
+            self.sizes = [int(n_own.item())]
+        self.n_max = max(max(self.sizes), 1)
+        parts = self._all_gather_padded(own_entries, self.n_max)
+        entries = torch.cat([p[:n] for p, n in zip(parts, self.sizes)])     # (rank, pixel) order
+        # group the contributions by voxel, keeping (rank, pixel) order inside a group
+        order = torch.argsort(entries, stable=True)
+        sorted_e = entries[order]
+        self.unique, self.inverse_sorted, counts = torch.unique_consecutive(sorted_e, return_inverse=True, return_counts=True)
+        starts = torch.cumsum(counts, 0) - counts
+        self.pos_in_group = torch.arange(sorted_e.numel(), device=self.dev) - starts[self.inverse_sorted]
+        self.order = order
+
+    def add_pass(self, own_rgb):
+        """own_rgb: int32 [n_own][3], this pass's contribution of each of this rank's hit pixels (same order as the
+        entries given to set_camera).  One all-gather, then the capped scatter-add into the replica."""
+        torch = self.torch
+        parts = self._all_gather_padded(own_rgb, self.n_max)
+        rgb = torch.cat([p[:n] for p, n in zip(parts, self.sizes)])[self.order].to(torch.int64)
+        u = self.unique
+        w0 = self.words[2 * u].to(torch.int64) & 0xFFFFFFFF
+        w1 = self.words[2 * u + 1].to(torch.int64) & 0xFFFFFFFF
+        count = w1 >> 16
+        remaining = torch.clamp(self.CAP - count, min=0)
+        keep = (self.pos_in_group < remaining[self.inverse_sorted]).to(torch.int64)
+        add = torch.zeros((u.numel(), 4), dtype=torch.int64, device=self.dev)
+        add.index_add_(0, self.inverse_sorted, torch.cat([rgb * keep[:, None], keep[:, None]], dim=1))
+        r = (w0 & 0xFFFF) + add[:, 0]
+        g = (w0 >> 16) + add[:, 1]
+        b = (w1 & 0xFFFF) + add[:, 2]
+        c = count + add[:, 3]
+        # <= 256 contributions of <= 255 each: every lane stays below 2^16
+        n0 = (r | (g << 16))
+        n1 = (b | (c << 16))
+        self.words[2 * u] = torch.where(n0 >= 2 ** 31, n0 - 2 ** 32, n0).to(torch.int32)
+        self.words[2 * u + 1] = torch.where(n1 >= 2 ** 31, n1 - 2 ** 32, n1).to(torch.int32)

@@ -64,6 +64,9 @@ class clw_function {
     clw_fail_hard_on_error(clwh_launch(m_kernel, global_size.data(), local_size.data(), args, (int)sizeof...(Args)));
   }
 
+  // not in the reference: the kernel handle, for the C ABI's entry points beyond the generic launch (clwh_render)
+  clwh_kernel *get_kernel() const { return m_kernel; }
+
  private:
   template <typename Arg>
   static void marshal(clwh_arg &out, const Arg &a) {

@@ -134,6 +134,13 @@ enum clwh_accum_mode {
   CLWH_ACCUM_VOXEL_CACHE = 0, /* reference-exact world-space cache (utility.cl:20-54) */
   CLWH_ACCUM_IMAGE_SPACE = 1  /* per-pixel float4 {r,g,b,count}, no token cap (multi-GPU tiles) */
 };
+/* Which of the reference's two shading functions `render` runs.  ray_marching.cl:186 calls compute_light; compute_ao
+ * (:104-149) is the alternate the authors kept in the file.  AO needs accum_mode CLWH_ACCUM_VOXEL_CACHE: it keeps
+ * {samples, occluded} as 2 ushorts per voxel in buffer_volume (utility.cl:123-159; at least clwh_cache_len()/2
+ * ushorts), capped at 100 samples per voxel.  compute_ao's return value has w == 0, which the reference's render()
+ * would overpaint with the environment colour (:187-195); here an AO hit pixel resolves to {v, v, v, 1},
+ * v = 2 * (100 - occluded), the value compute_ao returns. */
+enum clwh_shading { CLWH_SHADE_LIGHT = 0, CLWH_SHADE_AO = 1 };
 typedef struct clwh_render_desc {
   clwh_mem *frame;          /* RGBA8 2-D image; its dims are what get_image_width/height(frame) return */
   clwh_mem *volume;         /* S16 3-D image */
@@ -156,6 +163,10 @@ typedef struct clwh_render_desc {
                                n_seeds must stay below 2^24 (64 seeds: 16.7 M hit pixels), else
                                CLWH_ERR_INVALID_VALUE: use fewer seeds per launch */
   int32_t seeds[64];
+  int32_t shading;          /* enum clwh_shading; 0 (zero-initialised descriptors) = compute_light */
+  int32_t resolve_only;     /* 1: no pass; only resolve `frame` from buffer_volume / accum for this camera (the read-back
+                               half of compute_light, ray_marching.cl:82-99) -- e.g. after the cache was updated by an
+                               exchange between ranks */
 } clwh_render_desc;
 #define CLWH_MAX_SEEDS 64
 int clwh_render(clwh_kernel *render_kernel, const clwh_render_desc *desc);
@@ -190,6 +201,21 @@ int clwh_sdf_build(clwh_ctx *ctx, clwh_mem *volume, const char *tf_source, clwh_
 /* buffer_reset.cl:3-13 / app/renderer.cpp:32-35 */
 int clwh_buffer_reset(clwh_ctx *ctx, clwh_mem *buffer_volume);
 
+/* ---- display hand-off without a host readback.
+ * Replaces clw_foreign_memory::acquire / release (opencl_wrapper/include/clw_foreign_memory.hpp:40-46:
+ * clEnqueueAcquireGLObjects / clEnqueueReleaseGLObjects on a cl_mem made from a GL texture).  The frame the
+ * render kernels write is any device memory adopted with clwh_image_wrap -- the pointer a graphics-interop
+ * mapping (hipGraphicsResourceGetMappedPointer on a registered GL buffer) or another framework's allocator hands
+ * out -- so the frame never crosses PCIe.  Ordering between the context's stream and the consumer's stream is
+ * by HIP events, no host synchronisation:
+ *   clwh_ctx_acquire_from(ctx, s)  work queued on the context's stream after this call waits for everything
+ *                                  queued on stream `s` so far (the display has finished with the previous frame)
+ *   clwh_ctx_release_to(ctx, s)    work queued on stream `s` after this call waits for everything queued on the
+ *                                  context's stream so far (the frame is complete before the display reads it)
+ * `s` is a hipStream_t (NULL = the default stream). */
+int clwh_ctx_acquire_from(clwh_ctx *ctx, void *hip_stream);
+int clwh_ctx_release_to(clwh_ctx *ctx, void *hip_stream);
+
 /* ---- transfer function: the parsed form of the generated `is_event_gen` source */
 #define CLWH_TF_MAX_RULES 16
 typedef struct clwh_tf_rule {
@@ -215,6 +241,18 @@ const char *clwh_version(void);
  * clwh_ctx_timing_read waits for them, returns the summed duration and launch count, and resets. */
 int clwh_ctx_set_timing(clwh_ctx *ctx, int enabled);
 int clwh_ctx_timing_read(clwh_ctx *ctx, float *total_ms, int32_t *launches);
+/* the same per kernel of the render path: ms[k] / launches[k] for k < n, k = enum clwh_timer (HIP events on the
+ * context's stream around each launch; what bench.py's per-kernel roofline is computed from) */
+enum clwh_timer {
+  CLWH_TIMER_BOUNCE = 0,   /* k_bounce (the dominant kernel; what clwh_ctx_timing_read returns) */
+  CLWH_TIMER_PRIMARY = 1,  /* k_primary */
+  CLWH_TIMER_FIXUP = 2,    /* k_env_fixup + k_commit */
+  CLWH_TIMER_RESOLVE = 3,  /* k_resolve / k_accum_resolve */
+  CLWH_TIMER_REPACK = 4,   /* k_repack */
+  CLWH_TIMER_AO = 5,       /* k_ao */
+  CLWH_TIMER_COUNT = 6
+};
+int clwh_ctx_timing_read_all(clwh_ctx *ctx, float *ms, int32_t *launches, int32_t n);
 
 #ifdef __cplusplus
 }

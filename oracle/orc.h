@@ -63,10 +63,19 @@ enum {
   ORC_N_READ = 5,  /* cache reads (8 B) */
   ORC_N_HIT = 6,   /* pixel-samples whose primary march ended in Hit */
   ORC_N_STEP = 7,  /* march steps */
-  ORC_N_COUNTERS = 8
+  /* the part of N_SDF / N_VOL / N_ENV that belongs to the camera-dependent, seed-independent phase: the primary
+   * march (ray_marching.cl:33), the primary hit's normal (:42) and the environment lookups of miss pixels
+   * (:172-178, :188-195).  The MI355X build performs it once per camera (k_primary); the rest is the bounce phase. */
+  ORC_N_SDF_PRIMARY = 8,
+  ORC_N_VOL_PRIMARY = 9,
+  ORC_N_ENV_PRIMARY = 10,
+  ORC_N_COUNTERS = 12
 };
 
 enum { ORC_MODE_VOXEL_CACHE = 0, ORC_MODE_IMAGE_SPACE = 1 };
+/* which of the reference's two shading functions `render` calls (ray_marching.cl:186 calls compute_light; compute_ao,
+ * :104-149, is kept in the file as the alternate the authors swapped in by editing that line) */
+enum { ORC_SHADE_LIGHT = 0, ORC_SHADE_AO = 1 };
 
 typedef struct {
   const int16_t *volume;      /* x-fastest [z][y][x] */
@@ -89,11 +98,35 @@ typedef struct {
   uint64_t *counters;         /* optional, ORC_N_COUNTERS totals, accumulated */
   int32_t tile_rank, tile_world; /* image-tile partition: 8x8 tiles, owner = (tx+ty) % world */
   int32_t threads;            /* OpenMP threads (1 = deterministic sequential pixel order) */
+  int32_t shading;            /* ORC_SHADE_LIGHT (default) or ORC_SHADE_AO */
+  /* optional instrumentation of the bounce phase's march steps (tools/step_locality.py): */
+  uint64_t *locality;         /* ORC_LOC_COUNT totals, accumulated; NULL = off */
+  const uint8_t *uniform4;    /* optional, one byte per 4x4x4 sub-brick [z/4][y/4][x/4]: 1 = all 64 step bytes equal */
 } orc_render_params;
+
+/* locality[]: where the step fetches of the distribution rays fall (every fetch of a step byte = one SDF texel read) */
+enum {
+  ORC_LOC_FETCHES = 0,      /* step-byte fetches of the bounce phase that land inside the volume */
+  ORC_LOC_SAME_SUB4 = 1,    /* ... in the same 4x4x4 sub-brick (one 64-B line of step bytes) as the ray's previous fetch */
+  ORC_LOC_SAME_BRICK8 = 2,  /* ... in the same 8x8x8 brick */
+  ORC_LOC_NEAR_8 = 3,       /* ... within Chebyshev distance 8 / 16 / 32 / 64 voxels of the sample's PRIMARY hit */
+  ORC_LOC_NEAR_16 = 4,
+  ORC_LOC_NEAR_32 = 5,
+  ORC_LOC_NEAR_64 = 6,
+  ORC_LOC_UNIFORM4 = 7,     /* ... in a sub-brick whose 64 step bytes are all equal (uniform4 given) */
+  ORC_LOC_STEP_LE_1 = 8,    /* march steps of the bounce phase by length: <= 1, <= 2, <= 8, <= 32 voxels (cumulative) */
+  ORC_LOC_STEP_LE_2 = 9,
+  ORC_LOC_STEP_LE_8 = 10,
+  ORC_LOC_STEP_LE_32 = 11,
+  ORC_LOC_STEPS = 12,       /* march steps of the bounce phase */
+  ORC_LOC_COUNT = 16
+};
 
 /* number of ushorts the voxel cache needs so that the reference's latent one-row overrun
  * (position == dim, opencl_kernels/utility.cl:21 with utility_ray.cl:112-117) stays in bounds */
 int64_t orc_cache_len(int32_t X, int32_t Y, int32_t Z);
+/* ushorts the 2-channel {samples, occluded} view of the cache needs (compute_ao, utility.cl:123-159); half of the above */
+int64_t orc_ao_cache_len(int32_t X, int32_t Y, int32_t Z);
 
 /* opencl_kernels/ray_marching.cl:152-199 for every work-item of the NDRange */
 int orc_render(const orc_render_params *p);

@@ -17,9 +17,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "liborc.so")
 
 TF_MAX_RULES = 16
-N_COUNTERS = 8
-COUNTER_NAMES = ("n_sdf", "n_vol", "n_env", "n_tok", "n_add", "n_read", "n_hit", "n_step")
+N_COUNTERS = 12
+LOCALITY_NAMES = ("fetches", "same_sub4", "same_brick8", "near_8", "near_16", "near_32", "near_64", "uniform4",
+                  "step_le_1", "step_le_2", "step_le_8", "step_le_32", "steps")
+COUNTER_NAMES = ("n_sdf", "n_vol", "n_env", "n_tok", "n_add", "n_read", "n_hit", "n_step",
+                 "n_sdf_primary", "n_vol_primary", "n_env_primary", "reserved")
 MODE_VOXEL_CACHE, MODE_IMAGE_SPACE = 0, 1
+SHADE_LIGHT, SHADE_AO = 0, 1
 
 
 class TfRule(C.Structure):
@@ -57,6 +61,8 @@ class RenderParams(C.Structure):
         ("counters", C.c_void_p),
         ("tile_rank", C.c_int32), ("tile_world", C.c_int32),
         ("threads", C.c_int32),
+        ("shading", C.c_int32),
+        ("locality", C.c_void_p), ("uniform4", C.c_void_p),
     ]
 
 
@@ -240,7 +246,7 @@ class Scene:
     """Holds the numpy buffers of one oracle render job (so ctypes pointers stay alive)."""
 
     def __init__(self, volume, sdf, env, tf, frame_wh, launch_wh=None, mode=MODE_VOXEL_CACHE,
-                 tile_rank=0, tile_world=1, threads=1):
+                 tile_rank=0, tile_world=1, threads=1, shading=SHADE_LIGHT):
         self.volume = np.ascontiguousarray(volume, dtype=np.int16)
         self.sdf = np.ascontiguousarray(sdf, dtype=np.int8)
         self.env = np.ascontiguousarray(env, dtype=np.uint8)
@@ -251,7 +257,9 @@ class Scene:
         self.frame_w, self.frame_h = frame_wh
         self.launch_w, self.launch_h = launch_wh or frame_wh
         self.mode = mode
-        self.cache = np.zeros(cache_len(X, Y, Z), dtype=np.uint16)
+        self.shading = shading
+        # image-space mode never touches the world-space cache (64 GiB at 2048^3): only allocated when used
+        self.cache = np.zeros(cache_len(X, Y, Z), dtype=np.uint16) if (mode == MODE_VOXEL_CACHE or shading == SHADE_AO) else None
         self.frame = np.zeros((self.frame_h, self.frame_w, 4), dtype=np.uint8)
         npx = self.launch_w * self.launch_h
         self.accum = np.zeros((self.launch_h, self.launch_w, 4), dtype=np.float32)
@@ -259,6 +267,8 @@ class Scene:
         self.contrib = np.zeros((npx, 4), dtype=np.uint32)
         self.counters = np.zeros(N_COUNTERS, dtype=np.uint64)
         self.tile_rank, self.tile_world, self.threads = tile_rank, tile_world, threads
+        self.locality = None   # set to np.zeros(16, uint64) to collect the bounce phase's step-locality counters
+        self.uniform4 = None   # optional uint8 [ceil(Z/4)][ceil(Y/4)][ceil(X/4)] flags for the same instrumentation
 
     def _params(self, cam_pos, cam_dir, seed):
         X, Y, Z = self.dims
@@ -266,7 +276,7 @@ class Scene:
         p.volume, p.X, p.Y, p.Z = self.volume.ctypes.data, X, Y, Z
         p.sdf = self.sdf.ctypes.data
         p.env, p.env_w, p.env_h = self.env.ctypes.data, self.env.shape[1], self.env.shape[0]
-        p.cache = self.cache.ctypes.data
+        p.cache = self.cache.ctypes.data if self.cache is not None else None
         p.frame, p.frame_w, p.frame_h = self.frame.ctypes.data, self.frame_w, self.frame_h
         p.launch_w, p.launch_h = self.launch_w, self.launch_h
         for k in range(3):
@@ -280,6 +290,9 @@ class Scene:
         p.contrib = self.contrib.ctypes.data
         p.counters = self.counters.ctypes.data
         p.tile_rank, p.tile_world, p.threads = self.tile_rank, self.tile_world, self.threads
+        p.shading = self.shading
+        p.locality = self.locality.ctypes.data if self.locality is not None else None
+        p.uniform4 = self.uniform4.ctypes.data if self.uniform4 is not None else None
         return p
 
     def render(self, cam_pos, cam_dir, seed):
@@ -295,12 +308,13 @@ class Scene:
             raise RuntimeError("orc_resolve failed: %d" % rc)
 
     def reset(self):
-        self.cache[:] = 0
+        if self.cache is not None:
+            self.cache[:] = 0
         self.accum[:] = 0
         self.counters[:] = 0
 
     def counter_dict(self):
-        return {k: int(v) for k, v in zip(COUNTER_NAMES, self.counters)}
+        return {k: int(v) for k, v in zip(COUNTER_NAMES, self.counters) if k != "reserved"}
 
 
 def algorithmic_bytes(counters: dict, samples: int) -> float:

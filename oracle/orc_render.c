@@ -26,7 +26,39 @@ typedef struct {
   uint64_t c[ORC_N_COUNTERS];
   uint32_t gx, gy; /* get_global_id(0), get_global_id(1) */
   int tf_uses_gradient;
+  /* instrumentation only (orc_render_params.locality): never read by the algorithm */
+  uint64_t loc[ORC_LOC_COUNT];
+  int in_bounce;
+  int32_t hit_v[3];   /* voxel of the sample's primary hit */
+  int32_t prev_v[3];  /* voxel of the ray's previous step-byte fetch */
+  int have_prev;
 } ctx_t;
+
+static inline int32_t iabs32(int32_t v) { return v < 0 ? -v : v; }
+/* one step-byte fetch of the bounce phase at integer voxel (x, y, z) */
+static inline void loc_fetch(ctx_t *c, int32_t x, int32_t y, int32_t z) {
+  const orc_render_params *p = c->p;
+  if (!p->locality || !c->in_bounce) return;
+  if (x < 0 || y < 0 || z < 0 || x >= p->X || y >= p->Y || z >= p->Z) { c->have_prev = 0; return; }
+  c->loc[ORC_LOC_FETCHES]++;
+  if (c->have_prev) {
+    if ((x >> 2) == (c->prev_v[0] >> 2) && (y >> 2) == (c->prev_v[1] >> 2) && (z >> 2) == (c->prev_v[2] >> 2)) c->loc[ORC_LOC_SAME_SUB4]++;
+    if ((x >> 3) == (c->prev_v[0] >> 3) && (y >> 3) == (c->prev_v[1] >> 3) && (z >> 3) == (c->prev_v[2] >> 3)) c->loc[ORC_LOC_SAME_BRICK8]++;
+  }
+  int32_t dx = iabs32(x - c->hit_v[0]), dy = iabs32(y - c->hit_v[1]), dz = iabs32(z - c->hit_v[2]);
+  int32_t cheb = dx > dy ? dx : dy;
+  if (dz > cheb) cheb = dz;
+  if (cheb <= 8) c->loc[ORC_LOC_NEAR_8]++;
+  if (cheb <= 16) c->loc[ORC_LOC_NEAR_16]++;
+  if (cheb <= 32) c->loc[ORC_LOC_NEAR_32]++;
+  if (cheb <= 64) c->loc[ORC_LOC_NEAR_64]++;
+  if (p->uniform4) {
+    const int64_t sx = (p->X + 3) / 4, sy = (p->Y + 3) / 4;
+    if (p->uniform4[((int64_t)(z >> 2) * sy + (y >> 2)) * sx + (x >> 2)]) c->loc[ORC_LOC_UNIFORM4]++;
+  }
+  c->prev_v[0] = x; c->prev_v[1] = y; c->prev_v[2] = z;
+  c->have_prev = 1;
+}
 
 /* ---- fixed semantics of implementation-defined OpenCL built-ins (orc.h header) ---- */
 static inline float f_min(float a, float b) { return (b < a) ? b : a; }
@@ -83,6 +115,7 @@ static inline int32_t vol_read_f(ctx_t *c, float fx, float fy, float fz) {
 static inline int32_t sdf_read_i(ctx_t *c, i4 q) {
   const orc_render_params *p = c->p;
   c->c[ORC_N_SDF]++;
+  loc_fetch(c, q.x, q.y, q.z);
   if (!in_range(p, q.x, q.y, q.z)) return 0;
   return p->sdf[lin(p, q.x, q.y, q.z)];
 }
@@ -263,6 +296,13 @@ static inline ray_t march(ctx_t *c, ray_t cur) {
   float step_size = f_max(signed_distance, 0.5f);
   ray_t r = {v_add(cur.origin, v_scale(cur.direction, step_size)), cur.direction};
   c->c[ORC_N_STEP]++;
+  if (c->p->locality && c->in_bounce) {
+    c->loc[ORC_LOC_STEPS]++;
+    if (step_size <= 1.0f) c->loc[ORC_LOC_STEP_LE_1]++;
+    if (step_size <= 2.0f) c->loc[ORC_LOC_STEP_LE_2]++;
+    if (step_size <= 8.0f) c->loc[ORC_LOC_STEP_LE_8]++;
+    if (step_size <= 32.0f) c->loc[ORC_LOC_STEP_LE_32]++;
+  }
   return r;
 }
 
@@ -388,7 +428,10 @@ static u4 compute_light(ctx_t *c, ray_t surface_ray, int32_t random_seed, int64_
   const int information_dev = 1;
 
   int ray_event;
+  const uint64_t sdf0 = c->c[ORC_N_SDF], vol0 = c->c[ORC_N_VOL];
   current_ray = march_to_next_event(c, surface_ray, &ray_event, &current_color);
+  c->c[ORC_N_SDF_PRIMARY] += c->c[ORC_N_SDF] - sdf0;
+  c->c[ORC_N_VOL_PRIMARY] += c->c[ORC_N_VOL] - vol0;
   if (ray_event != EV_HIT) {
     u4 z = {0, 0, 0, 0};
     return z;
@@ -405,12 +448,20 @@ static u4 compute_light(ctx_t *c, ray_t surface_ray, int32_t random_seed, int64_
     granted = 1; /* image-space mode: no token, every sample contributes */
 
   if (granted) {
+    const uint64_t vol1 = c->c[ORC_N_VOL];
     const f3 normal = v_neg(v_normalize(gradient_nn(c, current_ray.origin)));
+    c->c[ORC_N_VOL_PRIMARY] += c->c[ORC_N_VOL] - vol1;
     float r_energy = (float)current_color.x / 255.0f;
     float g_energy = (float)current_color.y / 255.0f;
     float b_energy = (float)current_color.z / 255.0f;
 
+    {
+      i4 hv = make_int(hit_information.origin);
+      c->hit_v[0] = hv.x; c->hit_v[1] = hv.y; c->hit_v[2] = hv.z;
+      c->in_bounce = 1;
+    }
     for (int o = 1; o <= dist_count; ++o) {
+      c->have_prev = 0;
       current_ray = bounce_fake_reflectance(c, hit_information, normal, random_seed + o,
                                             ((float)current_color.w) / 255.0f);
       current_ray.origin = v_add(current_ray.origin, v_scale(normal, 2.0f));
@@ -441,6 +492,7 @@ static u4 compute_light(ctx_t *c, ray_t surface_ray, int32_t random_seed, int64_
         }
       }
     }
+    c->in_bounce = 0;
     buffer_value.x /= (uint32_t)dist_count;
     buffer_value.y /= (uint32_t)dist_count;
     buffer_value.z /= (uint32_t)dist_count;
@@ -474,6 +526,84 @@ static u4 compute_light(ctx_t *c, ray_t surface_ray, int32_t random_seed, int64_
   return tone_map(buffer_value);
 }
 
+
+/* ---- ambient occlusion: the reference's alternate shading function ------------------------------------------
+ * utility_sampling.cl:25-36 get_hemisphere_direction: like the reflective variant without the roughness blend */
+static inline f3 hemisphere_direction(uint32_t gx, uint32_t gy, f3 normal, int32_t seed) {
+  uint32_t useed = (uint32_t)seed + (gx + 1u) * (gy + 1u);
+  int32_t rx = (int32_t)orc_hash(useed * 0x182205bdu);
+  int32_t ry = (int32_t)orc_hash(useed * 0xe8d052f3u);
+  int32_t rz = (int32_t)orc_hash(useed * 0xf1981dcfu);
+  f3 direction = {(float)((rx % 2048) - 1024), (float)((ry % 2048) - 1024),
+                  (float)((rz % 2048) - 1024)};
+  float decider = v_dot(direction, normal);
+  return v_normalize(v_scale(direction, decider));
+}
+
+/* utility.cl:123-135 / :147-159 buffer_volume_read(f) / buffer_volume_write(f): the 2-channel view of the cache,
+ * idx = (X*Z*y + X*z + x) * 2 ushorts = {samples, occluded} per voxel */
+int64_t orc_ao_cache_len(int32_t X, int32_t Y, int32_t Z) {
+  return ((int64_t)X * Z * Y + (int64_t)X * Z + X + 1) * 2;
+}
+static inline int ao_entry_valid(const orc_render_params *p, int64_t e) {
+  return e >= 0 && (e + 1) * 2 <= orc_ao_cache_len(p->X, p->Y, p->Z);
+}
+
+/* ray_marching.cl:104-149 compute_ao.  The reference's read-modify-write of the cache entry is not atomic; this
+ * restatement runs the pixels one after the other, which is one legal outcome of that race, and the entry is
+ * order-independent while its sample count stays below the cap of 100.  Returns {v, v, v, 0} with
+ * v = 2 * (100 - occluded); note w == 0: plugged into render() as it stands (:186-195) every AO pixel would be
+ * painted with the environment colour, so *shade carries the value for the caller's resolve instead. */
+static u4 compute_ao(ctx_t *c, ray_t surface_ray, int32_t random_seed, int64_t *hit_entry, u4 *contribution) {
+  const orc_render_params *p = c->p;
+  ray_t current_ray = surface_ray;
+  ray_t hit_information;
+  memset(&hit_information, 0, sizeof hit_information);
+  i4 color = {0, 0, 0, 0};
+  int ray_event;
+  const uint64_t sdf0 = c->c[ORC_N_SDF], vol0 = c->c[ORC_N_VOL];
+  current_ray = march_to_next_event(c, surface_ray, &ray_event, &color);
+  c->c[ORC_N_SDF_PRIMARY] += c->c[ORC_N_SDF] - sdf0;
+  c->c[ORC_N_VOL_PRIMARY] += c->c[ORC_N_VOL] - vol0;
+  if (ray_event != EV_HIT) {
+    u4 z = {0, 0, 0, 0};
+    return z; /* `return 0.0f;` */
+  }
+  c->c[ORC_N_HIT]++;
+  const int64_t entry = cache_entry(p, make_int(current_ray.origin));
+  *hit_entry = entry;
+  if (!ao_entry_valid(p, entry)) { /* outside the allocation: nothing recorded, nothing occluded */
+    u4 z = {200, 200, 200, 0};
+    return z;
+  }
+  uint16_t *bv = p->cache + entry * 2;
+  uint32_t samples = bv[0], occluded = bv[1];
+  c->c[ORC_N_READ]++;
+  hit_information = current_ray;
+  if (samples < 100u) {
+    samples += 1u;
+    const uint64_t vol1 = c->c[ORC_N_VOL];
+    const f3 normal = v_neg(v_normalize(gradient_nn(c, current_ray.origin)));
+    c->c[ORC_N_VOL_PRIMARY] += c->c[ORC_N_VOL] - vol1;
+    /* utility_ray.cl:100-103 ray_bounce */
+    ray_t b = {v_add(current_ray.origin, current_ray.direction), hemisphere_direction(c->gx, c->gy, normal, random_seed)};
+    current_ray = b;
+    for (int k = 0; k < 7; ++k) current_ray = march(c, current_ray); /* seven unclassified steps */
+    march_to_next_event(c, current_ray, &ray_event, &color);
+    if (ray_event == EV_HIT) occluded += 1u;
+    bv[0] = (uint16_t)samples;
+    bv[1] = (uint16_t)occluded;
+    c->c[ORC_N_ADD]++;
+    contribution->x = (ray_event == EV_HIT) ? 1u : 0u;
+    contribution->w = 1u;
+  }
+  c->c[ORC_N_READ]++;
+  const uint32_t v = (100u - bv[1]) * 2u;
+  u4 r = {v, v, v, 0};
+  (void)hit_information;
+  return r;
+}
+
 /* ray_marching.cl:152-199 render, one work-item */
 static void render_pixel(ctx_t *c, uint32_t x, uint32_t y) {
   const orc_render_params *p = c->p;
@@ -501,6 +631,7 @@ static void render_pixel(ctx_t *c, uint32_t x, uint32_t y) {
 
   if (!cut_ok) {
     u4 e = sample_environment_map(c, vray.direction);
+    c->c[ORC_N_ENV_PRIMARY]++;
     u4 color = {e.x, e.y, e.z, 200};
     frame_write(p, x, y, color);
     return;
@@ -509,9 +640,17 @@ static void render_pixel(ctx_t *c, uint32_t x, uint32_t y) {
   ray_t surface_ray = {cut_point, vray.direction};
   int64_t hit_entry = -1;
   u4 contribution = {0, 0, 0, 0};
-  u4 f = compute_light(c, surface_ray, p->seed, &hit_entry, &contribution);
+  u4 f;
+  if (p->shading == ORC_SHADE_AO) {
+    f = compute_ao(c, surface_ray, p->seed, &hit_entry, &contribution);
+    /* compute_ao's result has w == 0 (see there); a hit pixel is shown as {v, v, v, 1} like compute_light's */
+    if (hit_entry != -1) f.w = 1;
+  } else {
+    f = compute_light(c, surface_ray, p->seed, &hit_entry, &contribution);
+  }
   if (f.w == 0) {
     u4 e = sample_environment_map(c, vray.direction);
+    c->c[ORC_N_ENV_PRIMARY]++;
     u4 color = {e.x, e.y, e.z, 200};
     frame_write(p, x, y, color);
     return;
@@ -537,7 +676,7 @@ static inline int tile_owned(const orc_render_params *p, uint32_t x, uint32_t y)
 
 int orc_render(const orc_render_params *p) {
   if (!p || !p->volume || !p->sdf || !p->env || !p->tf) return -1;
-  if (p->mode == ORC_MODE_VOXEL_CACHE && !p->cache) return -1;
+  if ((p->mode == ORC_MODE_VOXEL_CACHE || p->shading == ORC_SHADE_AO) && !p->cache) return -1;
   if (p->mode == ORC_MODE_IMAGE_SPACE && !p->accum) return -1;
   const int uses_g = tf_uses_gradient(p->tf);
   uint64_t total[ORC_N_COUNTERS];
@@ -555,7 +694,11 @@ int orc_render(const orc_render_params *p) {
       for (int32_t x = 0; x < p->launch_w; ++x)
         if (tile_owned(p, (uint32_t)x, (uint32_t)y)) render_pixel(&c, (uint32_t)x, (uint32_t)y);
 #pragma omp critical
-    for (int k = 0; k < ORC_N_COUNTERS; ++k) total[k] += c.c[k];
+    {
+      for (int k = 0; k < ORC_N_COUNTERS; ++k) total[k] += c.c[k];
+      if (p->locality)
+        for (int k = 0; k < ORC_LOC_COUNT; ++k) p->locality[k] += c.loc[k];
+    }
   }
   if (p->counters)
     for (int k = 0; k < ORC_N_COUNTERS; ++k) p->counters[k] += total[k];
@@ -571,6 +714,12 @@ int orc_resolve(const orc_render_params *p) {
       const int64_t e = p->hit_index[pix];
       if (e < 0) continue;
       u4 bv;
+      if (p->shading == ORC_SHADE_AO) {
+        const uint32_t v = ao_entry_valid(p, e) ? (100u - p->cache[e * 2 + 1]) * 2u : 200u;
+        u4 shade = {v, v, v, 1};
+        frame_write(p, (uint32_t)x, (uint32_t)y, shade);
+        continue;
+      }
       if (p->mode == ORC_MODE_VOXEL_CACHE) {
         if (!cache_entry_valid(p, e)) continue;
         bv = buffer_volume_read4(p, e);

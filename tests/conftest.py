@@ -24,6 +24,19 @@ def pytest_sessionstart(session):
             product_build.build_host()
     except Exception as e:  # the tests that need the libraries will fail loudly with the real reason
         print("warning: could not build the product libraries:", e, file=sys.stderr)
+    # On a GPU box PyTorch (ROCm 7.0 runtime inside the wheel) and libclwhip.so (the image's ROCm 7.2 runtime) both live
+    # in the test process (torch only as a stand-in for "another owner of device memory" in the hand-off tests and for
+    # the 64 GiB cache of the 2048^3 test).  Whichever HIP runtime comes SECOND finds the device when torch's came first,
+    # but torch reports "no ROCm-capable device" when libclwhip.so initialised the GPU before it -- so torch goes first,
+    # exactly as in bench.py.  (No GPU in the build container: nothing happens there.)
+    if os.path.exists("/dev/kfd"):
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception as e:
+            print("warning: torch could not initialise the GPU:", e, file=sys.stderr)
 
 
 @pytest.fixture(scope="session")

@@ -31,7 +31,8 @@ class GpuScene:
         self.kernel = ctx.kernel("ray_marching.cl", "render", tf_source)
         self.tf_source = tf_source
 
-    def render(self, pos, d, seed, mode=ffi.ACCUM_VOXEL_CACHE, rank=0, write_frame=True, debug=True, seeds=None):
+    def render(self, pos, d, seed, mode=ffi.ACCUM_VOXEL_CACHE, rank=0, write_frame=True, debug=True, seeds=None,
+               shading=ffi.SHADE_LIGHT):
         """seed: one pass; seeds: several passes in one launch (then no per-pixel contribution output)"""
         self.kernel.render(frame=self.frame, volume=self.volume, sdf=self.sdf, env=self.env,
                            buffer_volume=self.cache, accum=self.accum[rank], cam_pos=pos, cam_dir=d,
@@ -39,7 +40,7 @@ class GpuScene:
                            width=self.launch_w, height=self.launch_h, mode=mode, tile_rank=rank,
                            tile_world=self.world, write_frame=write_frame,
                            hit_index=self.hit_index if debug else None,
-                           contrib=self.contrib if (debug and seeds is None) else None)
+                           contrib=self.contrib if (debug and seeds is None) else None, shading=shading)
 
     def accum_row_major(self, rank=0):
         """tile-major float4 accumulation -> [h][w][4] with zeros for tiles the rank does not own."""

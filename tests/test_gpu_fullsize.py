@@ -156,3 +156,133 @@ def test_4k_frame_pass_matches_the_oracle(full, orc):
     assert np.array_equal(merged[hit][:, :3], o.contrib.reshape(h, w, 4)[hit][:, :3].astype(np.float32))
     assert np.all(merged[hit][:, 3] == 1) and not merged[~hit].any()
     g.release()
+
+
+def test_config3_gradient_tf_at_full_size(gpu_ctx, orc):
+    """BASELINE configs[2]: 512^3, 1920x1080, the gradient-reading transfer function (7 texels per step in the
+    reference) -- two whole passes against the oracle at full size, then the 256-spp job's size-independent
+    properties: image-space counts, the token cap in the reference-exact mode (reached here, unlike at 64 spp)."""
+    vol = scene.phantom(N)
+    env = scene.env_map(4096, 2048)
+    tf = scene.tf_gradient_source()
+    g = GpuScene(gpu_ctx, vol, None, env, tf, (W, H))
+    gpu_ctx.sdf_build(g.volume, tf, g.sdf)
+    sdf = g.sdf.pull()
+    pos, d = scene.default_camera(N)
+    threads = min(16, len(os.sched_getaffinity(0)))
+    o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (W, H), threads=threads)
+    seeds = scene.glibc_rand(256)
+    for s in seeds[:2]:
+        g.render(pos, d, s)
+        o.render(pos, d, s)
+    assert np.array_equal(g.hit_index.pull(), o.hit_index)
+    assert np.array_equal(g.contrib.pull(), o.contrib)
+    assert np.array_equal(g.cache.pull(), o.cache)
+    o.resolve(pos, d)
+    assert np.array_equal(g.frame.pull(), o.frame)
+    n_hit = int((o.hit_index >= 0).sum())
+    assert n_hit > 300000
+    # per-step counts: the gradient TF really takes the 7-texel route in the oracle
+    c = o.counter_dict()
+    assert c["n_vol"] > 6 * c["n_step"] * 0.9
+    del o
+    # 256 spp, image space, four launches of 64 passes
+    gpu_ctx.buffer_reset(g.accum[0])
+    for k in range(0, 256, 64):
+        g.render(pos, d, None, mode=ffi.ACCUM_IMAGE_SPACE, seeds=seeds[k:k + 64], debug=False, write_frame=False)
+    acc = g.accum[0].pull(np.float32).reshape(-1, 4)
+    assert set(np.unique(acc[:, 3])) == {0.0, 256.0} and int((acc[:, 3] > 0).sum()) == n_hit
+    assert acc[:, :3].max() <= 256 * 255
+    # 256 spp, reference-exact voxel cache, one pass per launch: the cap is reached and never exceeded
+    gpu_ctx.buffer_reset(g.cache)
+    for s in seeds:
+        g.render(pos, d, s, debug=False, write_frame=False)
+    cache = g.cache.pull().reshape(-1, 4)
+    hit_entries, per_voxel = np.unique(g.hit_index.pull()[g.hit_index.pull() >= 0], return_counts=True)
+    assert cache[:, 3].max() == 256 and (cache[:, 3] == 256).sum() > 1000
+    assert np.array_equal(cache[hit_entries, 3], np.minimum(per_voxel * 256, 256))   # min(requests, 256) per voxel
+    assert int((cache[:, 3] > 0).sum()) == hit_entries.size
+    assert cache[:, :3].max() <= 256 * 255
+    g.release()
+
+
+def test_config4_2048_volume_on_one_gpu(gpu_ctx, orc):
+    """BASELINE configs[3]: a 2048^3 volume (16 GiB of voxels, 8 GiB SDF, 40 GiB packed records, 64 GiB voxel cache:
+    every byte offset is 64-bit; the reference cannot run this at all, utility.cl:21 int index).
+    SDF: size-independent properties.  Render: two passes on a reduced launch against the oracle -- per-pixel hit voxel
+    and contribution, the image-space accumulation, and the voxel cache compared on the device at exactly the touched
+    entries (the oracle uses its image-space mode so the host needs no 64 GiB cache)."""
+    import torch
+
+    n = 2048
+    threads = min(16, len(os.sched_getaffinity(0)))
+    vol = scene.phantom_mt(n, threads=threads)
+    env = scene.env_map(1024, 512)
+    tf = scene.tf_default_source()
+    w, h = 640, 360
+    ctx = gpu_ctx
+    d_vol = ctx.image_from(vol)
+    d_sdf = ctx.image([n, n, n], 1, np.int8, (n, n, n))
+    n_layers = ctx.sdf_build(d_vol, tf, d_sdf)
+    sdf = d_sdf.pull()
+    assert n_layers % 2 == 1
+    # outside the ball the field saturates at max_iterations = 127; inside the 123-voxel shell it bottoms out near -61
+    assert int(sdf.max()) == 127 and -70 < int(sdf.min()) < -50 and not (sdf == 0).any()
+    for z0 in (0, 1000, 2040):               # sign == event class, slab by slab (whole-volume temporaries would be 8 GiB each)
+        sl = slice(z0, z0 + 8)
+        assert np.array_equal(sdf[sl] < 0, (vol[sl] >= 500) & (vol[sl] <= 1200))
+    a = np.abs(sdf[1399:1411].astype(np.int16))   # the recurrence: a settled value k > 1 has a corner neighbour holding k - 1
+    core = a[1:-1, 1:-1, 1:-1]
+    m = np.full(core.shape, 127, np.int16)
+    for dz in (0, 2):
+        for dy in (0, 2):
+            for dx in (0, 2):
+                m = np.minimum(m, a[dz:dz + core.shape[0], dy:dy + core.shape[1], dx:dx + core.shape[2]])
+    settled = (core > 1) & (core < 127)
+    assert settled.sum() > 1000000 and np.array_equal(core[settled], m[settled] + 1)
+    del a, core, m, settled
+
+    d_env = ctx.image_from(env, channels=4)
+    d_frame = ctx.image([w, h], 4, np.uint8, (h, w, 4))
+    n_cache = ffi.cache_len(n, n, n)
+    cache = torch.zeros(n_cache // 2, dtype=torch.int32, device="cuda")      # 64 GiB
+    m_cache = ctx.wrap(cache.data_ptr(), n_cache * 2)
+    m_accum = ctx.buffer(ffi.accum_len(w, h, 1) * 16, np.float32)
+    ctx.buffer_reset(m_accum)
+    m_hit = ctx.buffer(w * h * 8, np.int64)
+    m_contrib = ctx.buffer(w * h * 16, np.uint32, (w * h, 4))
+    k = ctx.kernel("ray_marching.cl", "render", tf)
+    pos, d = scene.default_camera(n)
+    o = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (w, h), mode=orc.MODE_IMAGE_SPACE, threads=threads)
+    assert o.cache is None
+    total = np.zeros((w * h, 4), np.int64)
+    for s in scene.glibc_rand(2):
+        k.render(frame=d_frame, volume=d_vol, sdf=d_sdf, env=d_env, buffer_volume=m_cache, cam_pos=pos, cam_dir=d, seed=s,
+                 width=w, height=h, mode=ffi.ACCUM_VOXEL_CACHE, hit_index=m_hit, contrib=m_contrib)
+        o.render(pos, d, s)
+        assert np.array_equal(m_hit.pull(), o.hit_index)
+        assert np.array_equal(m_contrib.pull(), o.contrib)
+        total += o.contrib
+        k.render(frame=None, volume=d_vol, sdf=d_sdf, env=d_env, accum=m_accum, cam_pos=pos, cam_dir=d, seed=s,
+                 width=w, height=h, mode=ffi.ACCUM_IMAGE_SPACE, write_frame=False)
+    hits = o.hit_index[o.hit_index >= 0]
+    assert hits.size > 20000
+    assert (hits * 8 > 2 ** 35).any(), "cache byte offsets beyond 32 GiB must really be exercised"
+    # image-space accumulation (tile-major with one rank) vs the oracle's
+    acc = m_accum.pull(np.float32).reshape(h // 8, w // 8, 8, 8, 4).transpose(0, 2, 1, 3, 4).reshape(h, w, 4)
+    assert np.array_equal(acc, o.accum)
+    # voxel cache: at exactly the touched entries, the scatter-add of the per-pixel contributions (counts stay far below 256)
+    entries, inv = np.unique(hits, return_inverse=True)
+    want = np.zeros((entries.size, 4), np.int64)
+    np.add.at(want, inv, total[o.hit_index >= 0])
+    e = torch.from_numpy(entries).cuda()
+    w0 = cache[2 * e].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    w1 = cache[2 * e + 1].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+    got = np.stack([w0 & 0xFFFF, w0 >> 16, w1 & 0xFFFF, w1 >> 16], axis=1)
+    assert want[:, 3].max() < 256 and np.array_equal(got, want)
+    assert int(torch.count_nonzero(cache).item()) == int(np.count_nonzero(w0) + np.count_nonzero(w1))   # nothing else was touched
+    for mobj in (d_vol, d_sdf, d_env, d_frame, m_accum, m_hit, m_contrib):
+        mobj.release()
+    k.release()
+    del cache
+    torch.cuda.empty_cache()

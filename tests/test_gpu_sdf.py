@@ -91,3 +91,36 @@ def test_unknown_kernel_and_bad_ndrange_are_reported(gpu_ctx):
         k.launch([10, 8, 1], [4, 4, 1])  # clw_function.hpp:235 asserts global % local == 0
     assert e.value.status == 8
     k.release()
+
+
+def test_full_sdf_at_256_equals_the_oracle(gpu_ctx, orc):
+    """every one of the 16.8 M values and the reference's launch count, against the oracle run here (about 15 s of CPU)"""
+    vol = scene.phantom(256)
+    tf = scene.tf_default_source()
+    v, s = _upload(gpu_ctx, vol)
+    n = gpu_ctx.sdf_build(v, tf, s)
+    want, launches, _ = orc.sdf_build(vol, orc.parse_tf(tf))
+    assert np.array_equal(s.pull(), want)
+    assert n == launches
+    v.release(); s.release()
+
+
+@pytest.mark.parametrize("tf_name", ["default", "gradient"])
+def test_sdf_at_512_equals_the_committed_oracle_checksum(gpu_ctx, golden_dir, tf_name):
+    """the SDF the headline benchmark marches through (512^3; the 7-tap gradient TF of config 3 too): SHA-256, sums
+    and launch count of the ORACLE's field, computed once in the build container (5 min of CPU each,
+    tests/golden/make_sdf_checksums.py) and committed -- byte-for-byte equality without re-running the oracle."""
+    import hashlib
+    import json
+    import os
+
+    want = json.load(open(os.path.join(golden_dir, "sdf_phantom_checksums.json")))["phantom(512) %s tf" % tf_name]
+    vol = scene.phantom(512)
+    tf = scene.tf_default_source() if tf_name == "default" else scene.tf_gradient_source()
+    v, s = _upload(gpu_ctx, vol)
+    n = gpu_ctx.sdf_build(v, tf, s)
+    sdf = s.pull()
+    assert n == want["launches"]
+    assert int(sdf.astype(np.int64).sum()) == want["sum"]
+    assert hashlib.sha256(sdf.tobytes()).hexdigest() == want["sha256"]
+    v.release(); s.release()

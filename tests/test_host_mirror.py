@@ -497,3 +497,60 @@ def test_fail_hard_error_convention_without_a_device():
     assert out.returncode == 1
     assert "CLWH_ERR_NO_DEVICE" in out.stderr and "Exiting application" in out.stderr
     assert "File      :" in out.stderr and "Line      :" in out.stderr
+
+
+@pytest.mark.gpu
+def test_render_frame_device_hands_the_frame_over_without_a_readback(orc):
+    """SURVEY 8f rank 4 (clw_foreign_memory.hpp:10-51, ui.cpp:296-308): renderer::render_frame_device writes the
+    frame into device memory the DISPLAY owns (here a torch tensor stands in for the mapped GL buffer), ordered to
+    the display's stream by an event; the host never pulls the frame.  One pass, then four passes batched into one
+    launch: the cache and the frame equal the oracle given the same std::rand() seeds."""
+    import torch
+
+    L = _host()
+    L.clvr_host_render_frame_device.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int,
+                                                C.c_int, C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_int]
+    n = 48
+    vol = scene.phantom(n)
+    env = scene.env_map(256, 128)
+    tf = scene.tf_default_source()
+    pos = np.array([-110.0, 150.0, -110.0], np.float32)
+    look = np.array([0.1, 6.6], np.float32)
+    W, H = 512, 256
+    h = L.clvr_host_create()
+    L.clvr_host_load(h, vol.ctypes.data, n, n, n, env.ctypes.data, env.shape[1], env.shape[0])
+    L.clvr_host_flush(h, tf.encode())
+    C.CDLL("libc.so.6").srand(1)
+
+    display = torch.cuda.Stream()
+    shown = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")    # the display's buffer
+    torch.cuda.synchronize()
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    want_sdf, _, _ = orc.sdf_build(vol, orc.parse_tf(tf))
+    o = orc.Scene(vol, want_sdf, env, orc.parse_tf(tf), (W, H))
+    d = scene.camera_direction(look[0], look[1])
+    seeds = scene.glibc_rand(5)
+
+    L.clvr_host_render_frame_device(h, fp(pos), fp(look), W, H, 1, C.c_void_p(shown.data_ptr()), W, H,
+                                    C.c_void_p(display.cuda_stream), 1)
+    with torch.cuda.stream(display):
+        first = shown.clone()                 # "the blit": runs on the display's stream, after the frame is complete
+    o.render(pos, d, seeds[0])
+    o.resolve(pos, d)
+    display.synchronize()
+    assert np.array_equal(first.cpu().numpy(), o.frame)
+
+    L.clvr_host_render_frame_device(h, fp(pos), fp(look), W, H, 0, C.c_void_p(shown.data_ptr()), W, H,
+                                    C.c_void_p(display.cuda_stream), 4)
+    with torch.cuda.stream(display):
+        second = shown.clone()
+    for s in seeds[1:]:
+        o.render(pos, d, s)
+    o.resolve(pos, d)
+    display.synchronize()
+    cache = np.empty(L.clvr_host_cache_len(h), np.uint16)
+    L.clvr_host_pull_cache(h, cache.ctypes.data)
+    assert 0 < cache.reshape(-1, 4)[:, 3].max() < 256
+    assert np.array_equal(cache, o.cache)
+    assert np.array_equal(second.cpu().numpy(), o.frame)
+    L.clvr_host_destroy(h)

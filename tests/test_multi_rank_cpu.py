@@ -161,3 +161,68 @@ def test_voxel_cache_reduce_never_carries_between_lanes(tmp_path):
     assert got[1, :3].max() <= 255 * 256                              # fits the u16 lanes again
     assert got[2].tolist() == [256 * 10, 256 * 20, 256 * 30, 256]     # exactly on the cap: still the exact sum
     assert got[3].tolist() == [0, 0, 0, 0]
+
+
+CAP_W, CAP_H, CAP_PASSES = 384, 384, 8
+
+
+def _cap_scene(orc_ffi):
+    vol = scene.phantom(24)
+    tf = orc_ffi.parse_tf(scene.tf_default_source())
+    sdf, _, _ = orc_ffi.sdf_build(vol, tf)
+    env = scene.env_map(128, 64)
+    pos = np.array([-9.0, 20.0, -9.0], np.float32)
+    d = np.array([12.0, 12.0, 12.0], np.float32) - pos
+    return vol, sdf, env, tf, pos, (d / np.linalg.norm(d)).astype(np.float32)
+
+
+def _exchange_worker(rank, port, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from oracle import orc_ffi
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    vol, sdf, env, tf, pos, d = _cap_scene(orc_ffi)
+    sc = orc_ffi.Scene(vol, sdf, env, tf, (CAP_W, CAP_H), mode=orc_ffi.MODE_IMAGE_SPACE, tile_rank=rank, tile_world=WORLD)
+    n_entries = orc_ffi.cache_len(24, 24, 24) // 4
+    words = torch.zeros(n_entries * 2, dtype=torch.int32)
+    x = tiles.VoxelExchange(words, WORLD)
+    idx = None
+    for i, s in enumerate(scene.glibc_rand(CAP_PASSES)):
+        sc.render(pos, d, s)
+        if i == 0:
+            hit = torch.from_numpy(sc.hit_index)
+            idx = torch.nonzero((hit >= 0) & (hit < n_entries)).flatten()
+            x.set_camera(hit[idx])
+        x.add_pass(torch.from_numpy(sc.contrib.astype(np.int32))[idx, :3])
+    np.save(os.path.join(out_dir, "replica%d.npy" % rank), words.numpy().view(np.uint16))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_global_token_rule_across_two_ranks(orc, tmp_path):
+    """the reference's 256-token cap applied to the GLOBAL count of a voxel, pass by pass
+    (tiles.VoxelExchange).  On a scene that reaches the cap: the replicas of both ranks are identical; no voxel
+    exceeds 256 samples; the sample count of every voxel equals the single-rank cache's; every voxel below the cap
+    equals the single-rank cache entry bit for bit; capped voxels hold 256 contributions of <= 255."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_exchange_worker, args=(_free_port(), str(tmp_path)), nprocs=WORLD, join=True)
+    r0 = np.load(str(tmp_path / "replica0.npy")).reshape(-1, 4)
+    r1 = np.load(str(tmp_path / "replica1.npy")).reshape(-1, 4)
+    assert np.array_equal(r0, r1)
+    vol, sdf, env, tf, pos, d = _cap_scene(orc)
+    one = orc.Scene(vol, sdf, env, tf, (CAP_W, CAP_H))
+    for s in scene.glibc_rand(CAP_PASSES):
+        one.render(pos, d, s)
+    want = one.cache.reshape(-1, 4)[: r0.shape[0]]
+    assert want[:, 3].max() == 256 and (want[:, 3] == 256).sum() > 20, "the scene must reach the cap"
+    assert (want[:, 3] < 256).sum() > 20
+    assert r0[:, 3].max() == 256
+    assert np.array_equal(r0[:, 3], want[:, 3])
+    below = want[:, 3] < 256
+    assert np.array_equal(r0[below], want[below])
+    assert (r0[~below, :3].astype(np.int64) <= 255 * 256).all()

@@ -25,7 +25,7 @@ def main(d):
     print("%-60s %8s %12s %12s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "max_us", "pct"))
     for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
         print("%-60s %8d %12.1f %12.2f %12.2f %6.1f%%" % (k[:60], len(v), sum(v), sum(v) / len(v), max(v), 100 * sum(v) / tot))
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_req", "pmc_sq"):
         acc = defaultdict(lambda: defaultdict(list))
         for r in rows(os.path.join(d, sub, "**", "*counter_collection.csv")):
             acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -46,21 +46,29 @@ def main(d):
 
 
 def traffic_json(d, out_path):
-    """HBM-side traffic of the dominant kernel per launch, from the separate FETCH_SIZE and WRITE_SIZE passes
-    (KiB -> bytes; raw, see MI355X_MICROARCH.md: the x2 correction applies to wide streams, not to 64-B gathers)."""
+    """HBM-side traffic per launch of the render kernels from the separate FETCH_SIZE / WRITE_SIZE / TCC request passes
+    (counter KiB -> bytes, RAW: no correction applied here; what a counted fetch request is worth in bytes for this
+    access pattern is calibrated by tools/probes/miss_bytes_probe.hip)."""
     import json
 
-    vals = {}
-    for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    def mean_of(sub, kernel, counter):
         v = [float(r["Counter_Value"]) for r in rows(os.path.join(d, sub, "**", "*counter_collection.csv"))
-             if "k_bounce" in r["Kernel_Name"] and r["Counter_Name"] == name]
-        if not v:
-            return
-        vals[name] = sum(v) / len(v) * 1024.0
+             if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter]
+        return sum(v) / len(v) if v else None
+
+    out = {}
+    for kernel in ("k_bounce", "k_primary", "k_sdf_front", "k_repack"):
+        fetch, write = mean_of("pmc_fetch", kernel, "FETCH_SIZE"), mean_of("pmc_write", kernel, "WRITE_SIZE")
+        if fetch is None or write is None:
+            continue
+        e = {"fetch_bytes_raw": fetch * 1024.0, "write_bytes": write * 1024.0}
+        for c in ("TCC_MISS_sum", "TCC_HIT_sum"):
+            e[c] = mean_of("pmc_write", kernel, c)
+        for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_REQ_sum", "TCC_READ_sum"):
+            e[c] = mean_of("pmc_req", kernel, c)
+        out[kernel] = e
     with open(out_path, "w") as f:
-        json.dump({"kernel": "k_bounce", "fetch_bytes_per_launch": vals["FETCH_SIZE"], "write_bytes_per_launch": vals["WRITE_SIZE"],
-                   "launch": "bench.py default: 512^3, 1920x1080, 64 seeds in one launch",
-                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/profile_gpu.sh"}, f)
+        json.dump(out, f, indent=1)
 
 
 if __name__ == "__main__":
