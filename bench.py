@@ -562,6 +562,10 @@ def main():
             "unit": "GB/s",
             "frac": round(bounce_gbs / HBM_PEAK_GBS, 5),
             "traffic": round(tb["gb_per_launch"], 3) if tb else None,
+            "traffic_rate": ({"unit": "GB/s", "value": round(tb["gb_per_launch"] / (bounce_avg_ms * 1e-3), 1),
+                              "frac_of_peak": round(tb["gb_per_launch"] / (bounce_avg_ms * 1e-3) / HBM_PEAK_GBS, 4),
+                              "what": "bytes ACTUALLY moved at the L2's memory side per launch (profiled run) / this run's launch "
+                                      "duration: every missing 1-byte gather moves a 128-byte line"} if tb else None),
             "traffic_note": (tb or {}).get("note", "GB per launch from rocprofv3 --pmc (profiles/r02_traffic.json); null: this launch shape was not profiled"),
             "limiter": "dependent 1-byte gathers: L2-miss request rate and VALU issue, not HBM bytes (DESIGN.md 4)",
             "bytes_per_sample": round(bytes_bounce(c) / float(own_px), 3),

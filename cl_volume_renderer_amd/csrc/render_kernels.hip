@@ -68,9 +68,9 @@ __device__ __forceinline__ unsigned lane_id() { return prefix_count(~0ull); }
 // volume + SDF + transfer function -> bricked step bytes + hit records (packed_volume.hpp); one wave writes one
 // 4x4x4 sub-brick (64 B of step bytes, 512 B of hit records)
 __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
-  const size_t sub_id = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6);  // 64 consecutive voxels of a brick
   const size_t n_sub = (size_t)a.NBX * a.NBY * a.NBZ * 8u;
-  if (sub_id >= n_sub) return;
+  // grid-stride: a launch may not exceed 2^32 work-items, and 2048^3 has 2^27 sub-bricks of 64 voxels
+  for (size_t sub_id = (size_t)blockIdx.x * 4u + (threadIdx.x >> 6); sub_id < n_sub; sub_id += (size_t)gridDim.x * 4u) {
   const size_t brick = sub_id >> 3;
   const int bx = (int)(brick % (size_t)a.NBX);
   const int by = (int)((brick / (size_t)a.NBX) % (size_t)a.NBY);
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
   }
   a.grec[sub_id * 64u + lane] = r;
   a.stepb[sub_id * 64u + lane] = q;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(64) void k_accum_resolve(const RenderArgs a, const 
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_repack(const RepackArgs &a, hipStream_t s) {
   const size_t n_sub = (size_t)a.NBX * a.NBY * a.NBZ * 8u;
-  hipLaunchKernelGGL(k_repack, dim3((unsigned)((n_sub + 3u) / 4u)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_repack, dim3((unsigned)std::min<size_t>((n_sub + 3u) / 4u, (size_t)1u << 23)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
