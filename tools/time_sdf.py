@@ -10,6 +10,7 @@ sys.path.insert(0, ".")
 from cl_volume_renderer_amd import ffi, scene  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+torch.cuda.init()  # torch's HIP runtime first (see tests/conftest.py)
 ctx = ffi.Context(0)
 tf = scene.tf_default_source()
 small = np.zeros((n, n, n), np.int16)
@@ -17,7 +18,7 @@ small[n // 2 - 8: n // 2 + 8, n // 2 - 8: n // 2 + 8, n // 2 - 8: n // 2 + 8] = 
 for name, vol in (("phantom", scene.phantom(n)), ("16^3 cube in an empty volume", small)):
     d_vol = ctx.image_from(vol)
     d_sdf = ctx.image([n, n, n], 1, np.int8, (n, n, n))
-    for rep in range(2):
+    for rep in range(4):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         layers = ctx.sdf_build(d_vol, tf, d_sdf)
