@@ -110,8 +110,7 @@ static int ensure_classes(clwh_ctx *ctx, const std::shared_ptr<JitTf> &jit, cons
   unsigned long long *palette = ctx->jit_palette;
   int *error = reinterpret_cast<int *>(ctx->jit_palette + kColors);
   void *args[] = {&vol, &X, &Y, &Z, &cls, &palette, &max_colors, &error};
-  const size_t blocks = (voxels + 255u) / 256u;
-  if (blocks > 0x7fffffffu) return CLWH_ERR_INVALID_VALUE;
+  const size_t blocks = std::min<size_t>((voxels + 255u) / 256u, (size_t)1u << 23);  // the classifier strides over the rest
   HIP_TRY(hipModuleLaunchKernel(jit->classify, (unsigned)blocks, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
   unsigned long long host[kColors + 1];
   HIP_TRY(hipMemcpyAsync(host, ctx->jit_palette, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
@@ -422,6 +421,18 @@ int clwh_mem_release(clwh_mem *mem) {
   }
   delete mem;
   return rc;
+}
+
+int clwh_host_register(void *host, size_t bytes) {
+  if (!host || bytes == 0) return CLWH_ERR_INVALID_VALUE;
+  HIP_TRY(hipHostRegister(host, bytes, hipHostRegisterDefault));
+  return CLWH_OK;
+}
+
+int clwh_host_unregister(void *host) {
+  if (!host) return CLWH_ERR_INVALID_VALUE;
+  HIP_TRY(hipHostUnregister(host));
+  return CLWH_OK;
 }
 
 void *clwh_mem_device_ptr(clwh_mem *mem) { return mem ? mem->dptr : nullptr; }

@@ -33,8 +33,8 @@ static const char *kClassifier = R"(
 extern "C" __global__ void clvr_tf_classify(const short *vol, int X, int Y, int Z, unsigned char *cls,
                                             unsigned long long *palette, int max_colors, int *error) {
   const size_t n = (size_t)X * (size_t)Y * (size_t)Z;
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  // grid-stride: a launch may not exceed 2^32 work-items (2048^3 voxels = 2^33)
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
   const int x = (int)(i % (size_t)X), y = (int)((i / (size_t)X) % (size_t)Y), z = (int)(i / ((size_t)X * (size_t)Y));
   auto at = [&](int px, int py, int pz) -> int {
     if ((unsigned)px >= (unsigned)X || (unsigned)py >= (unsigned)Y || (unsigned)pz >= (unsigned)Z) return 0;
@@ -60,6 +60,7 @@ extern "C" __global__ void clvr_tf_classify(const short *vol, int X, int Y, int 
     if (!out) *error = 1;
   }
   cls[i] = out;
+  }
 }
 )";
 

@@ -90,6 +90,8 @@ _PROTOTYPES = [
     ("clwh_mem_push", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     ("clwh_mem_pull", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     ("clwh_mem_release", C.c_int, [C.c_void_p]),
+    ("clwh_host_register", C.c_int, [C.c_void_p, C.c_size_t]),
+    ("clwh_host_unregister", C.c_int, [C.c_void_p]),
     ("clwh_mem_device_ptr", C.c_void_p, [C.c_void_p]),
     ("clwh_mem_size", C.c_size_t, [C.c_void_p]),
     ("clwh_mem_mark_dirty", C.c_int, [C.c_void_p]),

@@ -46,6 +46,7 @@ class clw_image {
     const int flags = std::is_const<TDevice>::value ? CLWH_MEM_READ_ONLY : CLWH_MEM_READ_WRITE;
     clw_fail_hard_on_error(clwh_image_create(m_context->get_handle(), m_dimensions.data(), (int)ChannelSize,
                                              element_kind(), flags, &m_mem));
+    pin_host();
     if (push_on_construction) push();
   }
   // copying re-allocates a device image with the same host contents, like the reference
@@ -59,7 +60,9 @@ class clw_image {
     m_context = other.m_context;
     m_dimensions = other.m_dimensions;
     m_mem = other.m_mem;
-    m_host = std::move(other.m_host);
+    m_host = std::move(other.m_host);  // the buffer (and its page lock) changes owner, not address
+    m_pinned = other.m_pinned;
+    other.m_pinned = false;
     other.m_mem = nullptr;
     other.m_context = nullptr;
     return *this;
@@ -88,10 +91,21 @@ class clw_image {
       return sizeof(TInternal) == 1 ? CLWH_ELEM_S8 : (sizeof(TInternal) == 2 ? CLWH_ELEM_S16 : CLWH_ELEM_S32);
     return sizeof(TInternal) == 1 ? CLWH_ELEM_U8 : (sizeof(TInternal) == 2 ? CLWH_ELEM_U16 : CLWH_ELEM_U32);
   }
+  // Not in the reference: the host mirror of a frame-sized image (what every render_frame pulls; environment maps) is
+  // page-locked so that push() / pull() are single DMAs.  Volumes (pushed once, up to 16 GiB) are not worth locking.
+  // A failure to lock is not an error: transfers just stay staged.
+  void pin_host() {
+    const size_t bytes = m_host.size() * sizeof(TInternal);
+    if (bytes >= ((size_t)1 << 20) && bytes <= ((size_t)64 << 20))
+      m_pinned = clwh_host_register(m_host.data(), m_host.size() * sizeof(TInternal)) == CLWH_OK;
+  }
   void release() {
+    if (m_pinned && !m_host.empty()) (void)clwh_host_unregister(m_host.data());
+    m_pinned = false;
     if (m_mem) clw_fail_hard_on_error(clwh_mem_release(m_mem));
     m_mem = nullptr;
   }
+  bool m_pinned = false;
   clwh_mem *m_mem = nullptr;
   std::vector<TInternal> m_host;
   const clw_context *m_context;  // not owned

@@ -81,6 +81,11 @@ int clwh_image_wrap(clwh_ctx *ctx, void *device_ptr, const size_t dims[3], int c
 int clwh_mem_push(clwh_ctx *ctx, clwh_mem *mem, const void *host, size_t bytes);
 int clwh_mem_pull(clwh_ctx *ctx, clwh_mem *mem, void *host, size_t bytes);
 int clwh_mem_release(clwh_mem *mem);
+/* page-lock / unlock a host buffer the caller keeps pushing from or pulling into (the host mirror of a clw_image,
+ * e.g. the 8 MiB frame renderer::render_frame pulls after every pass, app/renderer.cpp:150): transfers then run as
+ * one DMA instead of being staged through the runtime's bounce buffers.  Optional; never changes results. */
+int clwh_host_register(void *host, size_t bytes);
+int clwh_host_unregister(void *host);
 void *clwh_mem_device_ptr(clwh_mem *mem);
 size_t clwh_mem_size(clwh_mem *mem);
 /* tell the shim that device code outside it rewrote the object (invalidates derived layouts) */
