@@ -617,10 +617,12 @@ def main():
                 "value": round(samples_per_job * k2 / t / 1e6, 3), "unit": "Msamples/s", "steps": k2,
                 "ms_per_step": round(t * 1e3 / k2, 4)}
 
-    if rank == 0 and world == 1 and not args.no_secondary and args.config == 2:
+    if rank == 0 and world == 1 and not args.no_secondary and args.config in (2, 3):
+        # cap ON: the reference's own accumulation (256 tokens per voxel), the job's SPP passes one per launch
         result["reference_exact_mode"] = run_voxel_single(ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, N, W, H,
                                                           job_seeds(0), torch, ffi)
-        result["drop_in_path"] = run_dropin(vol, env, tf_source, pos, torch)
+        if args.config == 2:
+            result["drop_in_path"] = run_dropin(vol, env, tf_source, pos, torch)
     if rank == 0:
         ctx.finish()  # raises if a render overflowed its fix-up buffer (results would be incomplete)
         print(json.dumps(result), flush=True)
