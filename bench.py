@@ -13,6 +13,10 @@ jobs of the headline config take only K x 5.5 ms, the K-step region is repeated 
 MIN_TIMED_SECONDS have been measured and the MEDIAN region is reported (every region's time is the max over
 ranks), so the number does not depend on --steps and does not rest on a 2 ms measurement.  Inputs (volume,
 SDF, env map, packed records) are resident in HBM before the clock starts; the frame stays in HBM.
+Consecutive frame jobs alternate between two HIP streams (--frames-in-flight, each stream with its own
+accumulation and frame buffers): every persistent launch ends with ~0.3 ms in which its last waves wait for
+their longest samples, and the next frame's primary hits and first waves fill the GPU meanwhile (+4 % on one
+GPU).  The per-kernel durations of the roofline are measured in a separate region with ONE frame at a time.
 
 `--gpus N` starts its own N ranks (torch.distributed.run as a child process, before this process touches a
 GPU) unless it already runs under a launcher; the ranks share ONE frame as interleaved 8x8 image tiles
@@ -340,6 +344,10 @@ def main():
                     help="image: float4 per pixel + one all-gather (the headline); voxel: the reference's world-space "
                          "cache, one pass per launch, contributions exchanged pass by pass under the global 256-token rule")
     ap.add_argument("--seeds-per-launch", type=int, default=64, help="render passes fused into one launch (1..64)")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="consecutive frame jobs alternate between this many HIP streams (each with its own accumulation and "
+                         "frame buffers), so that the next frame's primary hits and first waves fill the GPU while the last "
+                         "waves of the previous frame's persistent launch drain; 1 = strictly one frame after the other")
     args = ap.parse_args()
     preset = PRESETS[args.config]
     for key, val in preset.items():
@@ -423,11 +431,30 @@ def main():
                         backend, barrier, max_over_ranks, sdf_build_s, n_layers, torch, dist, ffi, scene, tiles)
         return
 
+    # ---- frame lanes: lane 0 runs on torch's current stream with the objects above; every further lane is another HIP
+    # stream with its own context (derived arrays, primary hits), accumulation and frame buffers over the SAME volume /
+    # SDF / env-map device memory (adopted with clwh_image_wrap, not copied)
     n_acc = ffi.accum_len(W, H, world)
-    accum = torch.zeros(n_acc * 4, dtype=torch.float32, device=dev)
-    accum_all = torch.zeros(n_acc * 4 * world, dtype=torch.float32, device=dev)
-    m_accum = ctx.wrap(accum.data_ptr(), accum.numel() * 4)
-    m_accum_all = ctx.wrap(accum_all.data_ptr(), accum_all.numel() * 4)
+    n_lanes = max(1, args.frames_in_flight)
+    lanes = []
+    for li in range(n_lanes):
+        if li == 0:
+            stream, lctx, lvol, lsdf, lenv, lframe, lkernel = torch.cuda.current_stream(), ctx, d_vol, d_sdf, d_env, d_frame, kernel
+        else:
+            stream = torch.cuda.Stream()
+            lctx = ffi.Context(local_rank, stream=stream.cuda_stream)
+            lvol = lctx.image_wrap(d_vol.device_ptr, [N, N, N], 1, np.int16, (N, N, N))
+            lsdf = lctx.image_wrap(d_sdf.device_ptr, [N, N, N], 1, np.int8, (N, N, N))
+            lenv = lctx.image_wrap(d_env.device_ptr, [args.env[0], args.env[1]], 4, np.uint8, (args.env[1], args.env[0], 4))
+            lframe = lctx.image([W, H], 4, np.uint8, (H, W, 4))
+            lkernel = lctx.kernel("ray_marching.cl", "render", tf_source)
+        with torch.cuda.stream(stream):
+            acc = torch.zeros(n_acc * 4, dtype=torch.float32, device=dev)
+            acc_all = torch.zeros(n_acc * 4 * world, dtype=torch.float32, device=dev)
+        lanes.append(dict(stream=stream, ctx=lctx, vol=lvol, sdf=lsdf, env=lenv, frame=lframe, kernel=lkernel, accum=acc,
+                          accum_all=acc_all, m_accum=lctx.wrap(acc.data_ptr(), acc.numel() * 4),
+                          m_accum_all=lctx.wrap(acc_all.data_ptr(), acc_all.numel() * 4)))
+    torch.cuda.synchronize()
 
     # seeds: the glibc rand() stream the never-seeded reference draws from, one per pass, continuing over the jobs
     n_jobs_max = WU + 1 + K * MAX_REGIONS + 64
@@ -437,28 +464,30 @@ def main():
         a = (j * SPP) % max(1, len(seed_stream) - SPP)
         return seed_stream[a:a + SPP]
 
-    def frame_job(j, pull=False):
+    def frame_job(j, pull=False, serial=False):
         """one step: camera -> primary hits -> SPP passes -> (gather) -> RGBA8 frame in HBM"""
-        ctx.invalidate_derived(scene=False, camera=True)  # the first frame after a camera move: k_primary runs
-        accum.zero_()
-        sd = job_seeds(j)
-        for i in range(0, SPP, S):
-            kernel.render(frame=None, volume=d_vol, sdf=d_sdf, env=d_env, accum=m_accum, cam_pos=pos, cam_dir=cdir,
-                          seed=0, seeds=sd[i:i + S], width=W, height=H, mode=ffi.ACCUM_IMAGE_SPACE, tile_rank=rank,
-                          tile_world=world, write_frame=False)
-        tiles.gather_accum(accum, accum_all, world)  # N>1: ONE RCCL all-gather of the float4 tiles over xGMI
-        ctx.accum_resolve(m_accum_all, world, W, H, d_frame, d_env, pos, cdir)
-        if pull:
-            return d_frame.pull()
+        ln = lanes[0 if serial else j % n_lanes]
+        with torch.cuda.stream(ln["stream"]):
+            ln["ctx"].invalidate_derived(scene=False, camera=True)  # the first frame after a camera move: k_primary runs
+            ln["accum"].zero_()
+            sd = job_seeds(j)
+            for i in range(0, SPP, S):
+                ln["kernel"].render(frame=None, volume=ln["vol"], sdf=ln["sdf"], env=ln["env"], accum=ln["m_accum"], cam_pos=pos,
+                                    cam_dir=cdir, seed=0, seeds=sd[i:i + S], width=W, height=H, mode=ffi.ACCUM_IMAGE_SPACE,
+                                    tile_rank=rank, tile_world=world, write_frame=False)
+            tiles.gather_accum(ln["accum"], ln["accum_all"], world)  # N>1: ONE RCCL all-gather of the float4 tiles over xGMI
+            ln["ctx"].accum_resolve(ln["m_accum_all"], world, W, H, ln["frame"], ln["env"], pos, cdir)
+            if pull:
+                return ln["frame"].pull()
         return None
 
-    def timed_region(first_job, k, pull=False):
+    def timed_region(first_job, k, pull=False, serial=False):
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for j in range(first_job, first_job + k):
-            frame_job(j, pull)
+            frame_job(j, pull, serial)
         torch.cuda.synchronize()
         barrier()
         torch.cuda.synchronize()
@@ -466,16 +495,22 @@ def main():
 
     job = 0
     est = []
-    for _ in range(WU + 1):  # warm-up jobs (+1 so the context's work buffers have their final size)
+    for _ in range(max(WU + 1, n_lanes)):  # warm-up jobs (every lane at least once: its work buffers get their final size)
         est.append(timed_region(job, 1))
         job += 1
     est_job = max_over_ranks([min(est)])[0]
     regions = 1 if args.single_region else max(1, min(MAX_REGIONS, int(math.ceil(MIN_TIMED_SECONDS / max(est_job * K, 1e-6)))))
-    ctx.set_timing(True)
     region_s = []
     for _ in range(regions):
         region_s.append(timed_region(job, K))
         job += K
+    # kernel durations for the roofline: HIP events around every launch, in a separate region in which the frame jobs run
+    # strictly one after the other on one stream -- with two frames in flight a launch's events would also span the time it
+    # shares the GPU with the other frame's kernels
+    k_serial = max(2, min(K, 10))
+    ctx.set_timing(True)
+    serial_s = timed_region(job, k_serial, serial=True)
+    job += k_serial
     timers = ctx.timing_read_all()
     ctx.set_timing(False)
     region_s = max_over_ranks(region_s)  # every region: the slowest rank's time
@@ -509,6 +544,9 @@ def main():
                 SPP, (SPP + S - 1) // S, S, "RCCL all-gather + " if world > 1 else ""),
             "accumulation": "image-space float4 per pixel, 8x8 tiles interleaved over ranks",
             "passes_per_launch": S,
+            "frames_in_flight": n_lanes,
+            "one_frame_at_a_time": {"steps": k_serial, "ms_per_step": round(max_over_ranks([serial_s])[0] * 1e3 / k_serial, 4),
+                                    "note": "the same jobs strictly serial on one stream; the per-kernel durations of the roofline come from this region"},
             "timed": {"regions": regions, "steps_per_region": K, "seconds_median": round(elapsed, 6),
                       "seconds_min": round(min(region_s), 6), "seconds_max": round(max(region_s), 6),
                       "seconds_total": round(sum(region_s), 4)},
@@ -526,7 +564,7 @@ def main():
         sdf_host = d_sdf.pull()
         osc = orc_ffi.Scene(vol, sdf_host, env, orc_ffi.parse_tf(tf_source), (W, H), mode=orc_ffi.MODE_IMAGE_SPACE,
                             tile_rank=0, tile_world=world, threads=threads)
-        first = job_seeds(WU + 1)
+        first = job_seeds(max(WU + 1, n_lanes))
         t0 = time.perf_counter()
         osc.render(pos, cdir, first[0])
         t1 = time.perf_counter() - t0
@@ -624,7 +662,8 @@ def main():
         if args.config == 2:
             result["drop_in_path"] = run_dropin(vol, env, tf_source, pos, torch)
     if rank == 0:
-        ctx.finish()  # raises if a render overflowed its fix-up buffer (results would be incomplete)
+        for ln in lanes:
+            ln["ctx"].finish()  # raises if a render overflowed its fix-up buffer (results would be incomplete)
         print(json.dumps(result), flush=True)
 
     barrier()

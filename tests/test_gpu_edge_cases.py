@@ -124,3 +124,19 @@ def test_env_map_swapped_under_a_fixed_camera(gpu_ctx, orc):
     assert np.array_equal(g.frame.pull(), oa.frame)
     old.release()
     g.release()
+
+
+def test_extreme_voxel_values_fill_the_17_bit_hit_record_fields(gpu_ctx, orc):
+    """hit records keep the voxel's central differences in 17 signed bits (csrc/packed_volume.hpp): a volume that
+    alternates between the int16 extremes produces differences of +-65535 and +-32768 against the zero border; normals,
+    contributions and cache must still equal the oracle's six literal taps."""
+    rng = np.random.default_rng(5)
+    vol = rng.choice(np.array([-32768, 32767, -32768, 32767, 0, 700, 1100], np.int16), size=(24, 24, 24)).astype(np.int16)
+    vol[8:16, 8:16, 8:16] = 32767
+    env = scene.env_map(64, 32)
+    tf = scene.tf_rect_source([(20000.0, 32767.0, 0.0, 4000.0, (1.0, 0.5, 0.25, 0.8)),
+                               (600.0, 1200.0, 0.0, 4000.0, (0.2, 0.9, 0.4, 0.3))])
+    pos, d = look_at_centre(vol, [-10, 30, -14])
+    hits = _parity(orc, gpu_ctx, vol, env, tf, (96, 96), pos, d, scene.glibc_rand(3))
+    assert hits > 2000
+    _parity(orc, gpu_ctx, vol, env, tf, (96, 96), pos, d, [77], mode="image")
