@@ -119,7 +119,13 @@ enum {
   ORC_LOC_STEP_LE_8 = 10,
   ORC_LOC_STEP_LE_32 = 11,
   ORC_LOC_STEPS = 12,       /* march steps of the bounce phase */
-  ORC_LOC_COUNT = 16
+  ORC_LOC_COUNT = 16,
+  /* followed, in the same array, by two histograms of march steps (the dependent chain a lane walks):
+   * [ORC_LOC_HIST_RAY + n]  distribution rays with n steps (n clamped to 255; a ray is at most 3 marches = 210 steps)
+   * [ORC_LOC_HIST_ITEM + n] samples (both distribution rays) with n steps (n clamped to 511) */
+  ORC_LOC_HIST_RAY = 16,
+  ORC_LOC_HIST_ITEM = 16 + 256,
+  ORC_LOC_TOTAL = 16 + 256 + 512
 };
 
 /* number of ushorts the voxel cache needs so that the reference's latent one-row overrun

@@ -18,6 +18,7 @@ _LIB_PATH = os.path.join(_HERE, "_build", "liborc.so")
 
 TF_MAX_RULES = 16
 N_COUNTERS = 12
+LOCALITY_TOTAL, LOCALITY_HIST_RAY, LOCALITY_HIST_ITEM = 16 + 256 + 512, 16, 16 + 256
 LOCALITY_NAMES = ("fetches", "same_sub4", "same_brick8", "near_8", "near_16", "near_32", "near_64", "uniform4",
                   "step_le_1", "step_le_2", "step_le_8", "step_le_32", "steps")
 COUNTER_NAMES = ("n_sdf", "n_vol", "n_env", "n_tok", "n_add", "n_read", "n_hit", "n_step",
@@ -267,7 +268,7 @@ class Scene:
         self.contrib = np.zeros((npx, 4), dtype=np.uint32)
         self.counters = np.zeros(N_COUNTERS, dtype=np.uint64)
         self.tile_rank, self.tile_world, self.threads = tile_rank, tile_world, threads
-        self.locality = None   # set to np.zeros(16, uint64) to collect the bounce phase's step-locality counters
+        self.locality = None   # set to np.zeros(LOCALITY_TOTAL, uint64) to collect the bounce phase's step-locality counters
         self.uniform4 = None   # optional uint8 [ceil(Z/4)][ceil(Y/4)][ceil(X/4)] flags for the same instrumentation
 
     def _params(self, cam_pos, cam_dir, seed):

@@ -27,7 +27,7 @@ typedef struct {
   uint32_t gx, gy; /* get_global_id(0), get_global_id(1) */
   int tf_uses_gradient;
   /* instrumentation only (orc_render_params.locality): never read by the algorithm */
-  uint64_t loc[ORC_LOC_COUNT];
+  uint64_t loc[ORC_LOC_TOTAL];
   int in_bounce;
   int32_t hit_v[3];   /* voxel of the sample's primary hit */
   int32_t prev_v[3];  /* voxel of the ray's previous step-byte fetch */
@@ -460,7 +460,9 @@ static u4 compute_light(ctx_t *c, ray_t surface_ray, int32_t random_seed, int64_
       c->hit_v[0] = hv.x; c->hit_v[1] = hv.y; c->hit_v[2] = hv.z;
       c->in_bounce = 1;
     }
+    const uint64_t item_start = c->c[ORC_N_STEP];
     for (int o = 1; o <= dist_count; ++o) {
+      const uint64_t ray_start = c->c[ORC_N_STEP];
       c->have_prev = 0;
       current_ray = bounce_fake_reflectance(c, hit_information, normal, random_seed + o,
                                             ((float)current_color.w) / 255.0f);
@@ -491,6 +493,14 @@ static u4 compute_light(ctx_t *c, ray_t surface_ray, int32_t random_seed, int64_
           b_energy *= (float)current_color.z / 255.0f;
         }
       }
+      if (p->locality) {
+        const uint64_t n = c->c[ORC_N_STEP] - ray_start;
+        c->loc[ORC_LOC_HIST_RAY + (n > 255 ? 255 : n)]++;
+      }
+    }
+    if (p->locality) {
+      const uint64_t n = c->c[ORC_N_STEP] - item_start;
+      c->loc[ORC_LOC_HIST_ITEM + (n > 511 ? 511 : n)]++;
     }
     c->in_bounce = 0;
     buffer_value.x /= (uint32_t)dist_count;
@@ -697,7 +707,7 @@ int orc_render(const orc_render_params *p) {
     {
       for (int k = 0; k < ORC_N_COUNTERS; ++k) total[k] += c.c[k];
       if (p->locality)
-        for (int k = 0; k < ORC_LOC_COUNT; ++k) p->locality[k] += c.loc[k];
+        for (int k = 0; k < ORC_LOC_TOTAL; ++k) p->locality[k] += c.loc[k];
     }
   }
   if (p->counters)

@@ -37,7 +37,7 @@ stepb = (np.maximum(sdf, 0).astype(np.uint8) | (((vol >= 500) & (vol <= 1200)).a
 s4 = stepb.reshape(n // 4, 4, n // 4, 4, n // 4, 4).transpose(0, 2, 4, 1, 3, 5).reshape(n // 4, n // 4, n // 4, 64)
 uniform4 = np.ascontiguousarray((s4.min(axis=3) == s4.max(axis=3)).astype(np.uint8))
 sc = orc_ffi.Scene(vol, sdf, env, tf, (w, h), mode=orc_ffi.MODE_IMAGE_SPACE, threads=len(os.sched_getaffinity(0)))
-sc.locality = np.zeros(16, np.uint64)
+sc.locality = np.zeros(orc_ffi.LOCALITY_TOTAL, np.uint64)
 sc.uniform4 = uniform4
 for s in scene.glibc_rand(passes):
     sc.render(pos, d, s)
@@ -55,3 +55,25 @@ print("fetch within R voxels (Chebyshev) of the sample's primary hit:  R=8 %.1f 
     100 * L[k] / f for k in ("near_8", "near_16", "near_32", "near_64")))
 print("fetch in a 4^3 sub-brick whose 64 step bytes are all equal: %.1f %%   (%.1f %% of the volume's sub-bricks are uniform)" % (
     100 * L["uniform4"] / f, 100.0 * uniform4.mean()))
+
+
+def percentiles(hist, qs):
+    cum = np.cumsum(hist)
+    return [int(np.searchsorted(cum, q * cum[-1])) for q in qs]
+
+
+ray = sc.locality[orc_ffi.LOCALITY_HIST_RAY:orc_ffi.LOCALITY_HIST_RAY + 256].astype(np.int64)
+item = sc.locality[orc_ffi.LOCALITY_HIST_ITEM:orc_ffi.LOCALITY_HIST_ITEM + 512].astype(np.int64)
+qs = (0.5, 0.9, 0.99, 0.999, 0.9999)
+print("march steps per distribution ray: mean %.1f, percentiles 50 / 90 / 99 / 99.9 / 99.99: %s, max %d" % (
+    (ray * np.arange(256)).sum() / ray.sum(), " / ".join(map(str, percentiles(ray, qs))), int(np.nonzero(ray)[0].max())))
+print("march steps per sample (two rays, one lane walks them back to back): mean %.1f, percentiles: %s, max %d" % (
+    (item * np.arange(512)).sum() / item.sum(), " / ".join(map(str, percentiles(item, qs))), int(np.nonzero(item)[0].max())))
+# a wave walks 64 samples in lock-step phases: its step phases last as long as its longest sample
+rng = np.random.default_rng(0)
+p_item = item / item.sum()
+draw = rng.choice(512, size=(20000, 64), p=p_item)
+p_ray = ray / ray.sum()
+draw_ray = rng.choice(256, size=(20000, 64), p=p_ray)
+print("expected longest of 64 independent samples: %.0f steps; of 64 independent single rays: %.0f steps" % (
+    draw.max(axis=1).mean(), draw_ray.max(axis=1).mean()))
