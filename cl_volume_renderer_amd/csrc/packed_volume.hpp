@@ -112,13 +112,7 @@ struct VolumePacked {
   template <bool SMALL = false>
   __device__ __forceinline__ uint2 hit_record(float fx, float fy, float fz) const {
     const unsigned ux = (unsigned)(int)fx, uy = (unsigned)(int)fy, uz = (unsigned)(int)fz;
-#ifdef CLVR_NT_HITREC  // experiment: non-temporal load of the record (a secondary hit's record is hardly ever reused)
-    const unsigned long long raw = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(grec) +
-                                                              (part_x<SMALL>(ux) + part_y<SMALL>(uy) + part_z<SMALL>(uz)));
-    return uint2{(uint32_t)raw, (uint32_t)(raw >> 32)};
-#else
     return grec[part_x<SMALL>(ux) + part_y<SMALL>(uy) + part_z<SMALL>(uz)];
-#endif
   }
 
   // the march's per-step byte: one 128-byte line holds two 4x4x4 sub-bricks, the whole 512^3 array is 128 MiB

@@ -158,11 +158,7 @@ __device__ __forceinline__ bool sample_environment_map_fast(const uint32_t *__re
                                                             uint32_t &texel) {
   int32_t i, j;
   if (!env_texel_fast(d.x, d.y, d.z, w, h, i, j)) return false;
-#ifdef CLVR_NT_ENV  // experiment: the texel is used once -- do not let it displace step-byte lines in L2
-  texel = __builtin_nontemporal_load(env + ((size_t)j * (size_t)w + (size_t)i));
-#else
   texel = env[(size_t)j * (size_t)w + (size_t)i];
-#endif
   return true;
 }
 

@@ -42,6 +42,33 @@ __global__ __launch_bounds__(256) void k_random(const unsigned char *__restrict_
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+// the same independent random loads with other cache policies: does any of them fetch less than a 128-byte line?
+template <int POLICY>
+__global__ __launch_bounds__(256) void k_random_policy(const unsigned char *__restrict__ t, size_t mask, int loads, unsigned *out) {
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long x = (unsigned long long)gid * 0x9E3779B97F4A7C15ull + 0x1234567ull;
+  unsigned acc = 0;
+#define CLVR_PROBE_LOAD(dst)                                                                                       \
+  do {                                                                                                             \
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;                                                                       \
+    const unsigned char *p = t + (x & mask);                                                                       \
+    if (POLICY == 0) asm volatile("global_load_ubyte %0, %1, off nt" : "=&v"(dst) : "v"(p) : "memory");            \
+    if (POLICY == 1) asm volatile("global_load_ubyte %0, %1, off sc0 sc1" : "=&v"(dst) : "v"(p) : "memory");       \
+    if (POLICY == 2) asm volatile("global_load_ubyte %0, %1, off sc1" : "=&v"(dst) : "v"(p) : "memory");           \
+    if (POLICY == 3) asm volatile("global_load_ubyte %0, %1, off sc0 sc1 nt" : "=&v"(dst) : "v"(p) : "memory");    \
+    if (POLICY == 4) asm volatile("global_load_ubyte %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");               \
+  } while (0)
+  for (int s = 0; s < loads; s += 8) {  // eight loads in flight per lane, then one wait
+    unsigned v0, v1, v2, v3, v4, v5, v6, v7;
+    CLVR_PROBE_LOAD(v0); CLVR_PROBE_LOAD(v1); CLVR_PROBE_LOAD(v2); CLVR_PROBE_LOAD(v3);
+    CLVR_PROBE_LOAD(v4); CLVR_PROBE_LOAD(v5); CLVR_PROBE_LOAD(v6); CLVR_PROBE_LOAD(v7);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(v4), "+v"(v5), "+v"(v6), "+v"(v7) : : "memory");
+    acc += v0 + v1 + v2 + v3 + v4 + v5 + v6 + v7;
+  }
+#undef CLVR_PROBE_LOAD
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
 int main() {
   const size_t X = 8ull << 30;
   unsigned char *t; unsigned *out;
@@ -65,6 +92,14 @@ int main() {
   const int loads = 64;
   const double L = (double)blocks * 256 * loads;
   const float tr = time_it("random", L, [&] { k_random<<<blocks, 256>>>(t, X - 1, loads, out); });
+  // (inline-asm loads, eight in flight per lane: these five compare with EACH OTHER first)
+  const int loads2 = 64;
+  const double L2 = (double)blocks * 256 * loads2;
+  time_it("rnd plain*", L2, [&] { k_random_policy<4><<<blocks, 256>>>(t, X - 1, loads2, out); });
+  time_it("rnd nt", L2, [&] { k_random_policy<0><<<blocks, 256>>>(t, X - 1, loads2, out); });
+  time_it("rnd sc0sc1", L2, [&] { k_random_policy<1><<<blocks, 256>>>(t, X - 1, loads2, out); });
+  time_it("rnd sc1", L2, [&] { k_random_policy<2><<<blocks, 256>>>(t, X - 1, loads2, out); });
+  time_it("rnd sc01nt", L2, [&] { k_random_policy<3><<<blocks, 256>>>(t, X - 1, loads2, out); });
   printf("time relative to the stream: stride32 %.2f  stride64 %.2f  stride128 %.2f  stride256 %.2f  stride512 %.2f\n", t32 / ts, t64 / ts, t128 / ts, t256 / ts, t512 / ts);
   printf("random: %.1f M independent 1-byte loads over 8 GiB in %.3f ms = %.1f G loads/s; at 64 B each %.2f TB/s, at 128 B each %.2f TB/s\n",
          L / 1e6, tr, L / tr / 1e6, L * 64 / tr / 1e9, L * 128 / tr / 1e9);
