@@ -249,6 +249,9 @@ __global__ __launch_bounds__(64 * CLVR_SDF_WAVES) void k_sdf_front(const SdfFron
           v.x = src[0]; v.y = src[1]; v.z = src[2]; v.w = src[3];
           *reinterpret_cast<uint4 *>(dst) = v;
         } else {
+          // bytes 0..2 and 13..15 of the row are never neighbours of an own voxel, but the packed-byte test below
+          // classifies whole dwords: keep them in the value range (an arbitrary 0x80 would carry into byte 3)
+          *reinterpret_cast<uint4 *>(dst) = uint4{0u, 0u, 0u, 0u};
 #pragma unroll
           for (int rx = 0; rx < 10; ++rx) dst[3 + rx] = row[min(max(x0 - 1 + rx, 0), a.X - 1)];
         }
@@ -266,34 +269,77 @@ __global__ __launch_bounds__(64 * CLVR_SDF_WAVES) void k_sdf_front(const SdfFron
       const int ly = (int)(lane & 7u), lz = (int)(lane >> 3);
       const int y = y0 + ly, z = z0 + lz;
       if (y < a.Y && z < a.Z) {
-        const int8_t *c = &s_region[wave][(lz + 1) * kSliceStride + (ly + 1) * kRowStride + 4];
-        int8_t *out = a.sdf + ((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x0;
+        // A lane owns the 8 voxels of one x-row of the tile.  The reference's test (signed_distance_field.cl:56-112)
+        //   |v| > it  and  the 8 corner neighbours all have one sign (zeros allowed)  and  their smallest |value| == it
+        // is evaluated for the 8 voxels at once on packed bytes: the four neighbouring rows (y+-1, z+-1) are read as four
+        // 16-byte LDS words, each byte is classified with carry-free SWAR arithmetic (all magnitudes are <= 127, so adding
+        // 0x7F / subtracting from 0x80 | x never crosses a byte), the per-row flags are AND / OR-ed over the four rows, and
+        // a voxel's corner neighbours are the flag bytes one to the left and one to the right of its own byte.  The first
+        // version read 72 single bytes per lane and spent ~550 VALU instructions per row of 8 voxels; the layers of the 512^3
+        // build were bound by exactly that arithmetic (profiles/r02_sdf_front_variants_negative_results.txt).
+        const uint32_t b1 = 0x01010101u, b80 = 0x80808080u, b7f = 0x7F7F7F7Fu;
+        const uint32_t itb = (uint32_t)it * b1, itp1b = (uint32_t)(it + 1) * b1, itp2b = (uint32_t)(it + 2) * b1;
+        const int8_t *own_row = &s_region[wave][(lz + 1) * kSliceStride + (ly + 1) * kRowStride];
+        uint32_t all_ne[4] = {~0u, ~0u, ~0u, ~0u}, all_ge[4] = {~0u, ~0u, ~0u, ~0u}, any_neg[4] = {0u, 0u, 0u, 0u},
+                 any_pos[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int lx = 0; lx < 8; ++lx) {
-          if (x0 + lx >= a.X) break;
-          const int v = c[lx];
-          bool still_open = abs(v) > it + 1;
-          if (abs(v) > it) {
-            int nd = 127, abs_added = 0, added = 0;
+        for (int q = 0; q < 4; ++q) {
+          const uint4 row = *reinterpret_cast<const uint4 *>(own_row + ((q & 1) ? kRowStride : -kRowStride) +
+                                                             ((q & 2) ? kSliceStride : -kSliceStride));
+          const uint32_t w[4] = {row.x, row.y, row.z, row.w};
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              const int nv = c[lx + ((q & 1) ? 1 : -1) + ((q & 2) ? kRowStride : -kRowStride) +
-                               ((q & 4) ? kSliceStride : -kSliceStride)];
-              const int an = (int)(int8_t)abs(nv);
-              abs_added += an;
-              added += nv;
-              nd = min(nd, an);
-            }
-            if (abs(added) == abs_added && nd != 0 && nd == it && it + 1 < a.max_iterations) {
-              // the reference only writes (and counts) values below max_iterations; +-max stays as it is
-              out[lx] = (int8_t)(v < 0 ? -(it + 1) : (it + 1));
-              ++settled;
-              still_open = false;
-              face_mask |= (lx == 0 ? 1u : 0u) | (lx == 7 ? 2u : 0u) | (ly == 0 ? 4u : 0u) | (ly == 7 ? 8u : 0u) |
-                           (lz == 0 ? 16u : 0u) | (lz == 7 ? 32u : 0u);
-            }
+          for (int d = 0; d < 4; ++d) {
+            const uint32_t sgn = (w[d] >> 7) & b1;
+            const uint32_t mag = (w[d] ^ ((sgn << 8) - sgn)) + sgn;  // |byte| per byte
+            all_ne[d] &= (mag ^ itb) + b7f;                          // bit 7: |byte| != it
+            all_ge[d] &= (mag | b80) - itb;                          // bit 7: |byte| >= it
+            any_neg[d] |= w[d];                                      // bit 7: byte < 0
+            any_pos[d] |= (mag + b7f) & ~w[d];                       // bit 7: byte > 0
           }
-          open_voxels |= still_open;
+        }
+        // flags of the bytes left (x - 1) and right (x + 1) of the own bytes 4..11, i.e. of dwords 1 and 2
+        auto left = [](const uint32_t *f, int d) { return (f[d] << 8) | (f[d - 1] >> 24); };
+        auto right = [](const uint32_t *f, int d) { return (f[d] >> 8) | (f[d + 1] << 24); };
+        const uint32_t *own_words = reinterpret_cast<const uint32_t *>(own_row + 4);  // 4-byte aligned: two dword reads
+        const uint32_t own[2] = {own_words[0], own_words[1]};
+        uint32_t settle[2], opened[2], fresh[2];
+        const bool can_settle = it + 1 < a.max_iterations;  // the reference only writes values below max_iterations
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int d = h + 1;
+          const uint32_t sgn = (own[h] >> 7) & b1, neg_mask = (sgn << 8) - sgn;
+          const uint32_t mag = (own[h] ^ neg_mask) + sgn;
+          const uint32_t unsettled = (mag | b80) - itp1b;                                   // |v| > it
+          const uint32_t eq_any = ~(left(all_ne, d) & right(all_ne, d));                    // some corner neighbour holds it
+          const uint32_t ge_all = left(all_ge, d) & right(all_ge, d);                       // none holds less (or zero)
+          const uint32_t mixed = (left(any_neg, d) | right(any_neg, d)) & (left(any_pos, d) | right(any_pos, d));
+          // voxels beyond the volume's x extent (last tile of a row when X is not a multiple of 8) do not exist
+          uint32_t valid = b80;
+          if (x0 + 8 > a.X) {
+            valid = 0u;
+#pragma unroll
+            for (int bx = 0; bx < 4; ++bx)
+              if (x0 + h * 4 + bx < a.X) valid |= 0x80u << (8 * bx);
+          }
+          settle[h] = can_settle ? (unsettled & eq_any & ge_all & ~mixed & valid) : 0u;
+          opened[h] = ((mag | b80) - itp2b) & ~settle[h] & valid;                           // |v| > it + 1 and not settled now
+          const uint32_t sel = settle[h] >> 7, sel_mask = (sel << 8) - sel;
+          fresh[h] = (own[h] & ~sel_mask) | (((itp1b ^ neg_mask) + sgn) & sel_mask);        // +-(it + 1) with the voxel's sign
+        }
+        settled = __popc(settle[0]) + __popc(settle[1]);
+        open_voxels = (opened[0] | opened[1]) != 0u;
+        if (settled) {
+          int8_t *out = a.sdf + ((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x0;
+          if (rows_aligned && x0 + 8 <= a.X) {
+            if (settle[0]) *reinterpret_cast<uint32_t *>(out) = fresh[0];
+            if (settle[1]) *reinterpret_cast<uint32_t *>(out + 4) = fresh[1];
+          } else {
+#pragma unroll
+            for (int lx = 0; lx < 8; ++lx)
+              if ((settle[lx >> 2] >> (8 * (lx & 3) + 7)) & 1u) out[lx] = (int8_t)(fresh[lx >> 2] >> (8 * (lx & 3)));
+          }
+          face_mask = ((settle[0] >> 7) & 1u) | ((settle[1] >> 31) ? 2u : 0u) | (ly == 0 ? 4u : 0u) | (ly == 7 ? 8u : 0u) |
+                      (lz == 0 ? 16u : 0u) | (lz == 7 ? 32u : 0u);
         }
       }
     }
