@@ -916,13 +916,17 @@ int clwh_sdf_build(clwh_ctx *ctx, clwh_mem *volume, const char *tf_source, clwh_
   a.tile_done = ctx->sdf_flags + 3 * n_tiles;
 
   // layers that can still settle a voxel: i + 1 < max_iterations; the host looks at the per-layer
-  // counts every 16 launches and stops once a layer settled nothing (nothing can change after it)
+  // counts every kSdfLayersPerCheck launches and stops once a layer settled nothing (nothing can change after it)
+#ifndef CLVR_SDF_LAYERS_PER_CHECK
+#define CLVR_SDF_LAYERS_PER_CHECK 32  // measured 16 / 32 / 64 / 128: 5.31 / 5.21 / 5.14 / 5.19 ms for the 512^3 build
+#endif
+  constexpr int kSdfLayersPerCheck = CLVR_SDF_LAYERS_PER_CHECK;
   const int last_layer = a.max_iterations - 2;
   std::vector<int32_t> settled(kSlots, 0);
   int i = 1;
   bool quiet = false;
   while (i <= last_layer && !quiet) {
-    const int chunk_end = std::min(last_layer, i + 15);
+    const int chunk_end = std::min(last_layer, i + kSdfLayersPerCheck - 1);
     for (; i <= chunk_end; ++i) {
       a.iteration = i;
       a.flags_cur = flags[i % 3];
