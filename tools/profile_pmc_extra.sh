@@ -6,7 +6,7 @@ TAG=${1:-extra}; shift
 OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out/pmcx_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --no-cpu-baseline --no-secondary --single-region --steps 2 --warmup 1 $*"
+BENCH="python3 bench.py --no-cpu-baseline --no-secondary --single-region --frames-in-flight 1 --steps 2 --warmup 1 $*"
 i=0
 while read -r SET; do
   [ -z "$SET" ] && continue
