@@ -12,7 +12,7 @@ to the RGBA8 frame.  `--steps K` times exactly K such jobs between barrier + syn
 jobs of the headline config take only K x 5.5 ms, the K-step region is repeated until at least
 MIN_TIMED_SECONDS have been measured and the MEDIAN region is reported (every region's time is the max over
 ranks), so the number does not depend on --steps and does not rest on a 2 ms measurement.  Inputs (volume,
-SDF, env map, packed records) are resident in HBM before the clock starts; the frame stays in HBM.
+SDF, env map, step bytes and hit records) are resident in HBM before the clock starts; the frame stays in HBM.
 Consecutive frame jobs alternate between two HIP streams (--frames-in-flight, each stream with its own
 accumulation and frame buffers): every persistent launch ends with ~0.3 ms in which its last waves wait for
 their longest samples, and the next frame's primary hits and first waves fill the GPU meanwhile (+4 % on one

@@ -92,7 +92,7 @@ struct RenderArgs {
   TfDev tf;
 };
 
-// ---- repack arguments (volume + sdf + TF -> packed records)
+// ---- repack arguments (volume + sdf + TF -> step bytes + hit records)
 struct RepackArgs {
   const int16_t *volume;
   const int8_t *sdf;

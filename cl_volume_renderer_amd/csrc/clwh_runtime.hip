@@ -511,7 +511,7 @@ static bool is_image(const clwh_mem *m, int dims_n, int channels, int elem_kind)
   return true;
 }
 
-// (re)build the packed {value, sdf, class} records when the volume, the SDF or the TF changed
+// (re)build the bricked step bytes + hit records (packed_volume.hpp) when the volume, the SDF or the TF changed
 static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *sdf, const TfDev &tf, const uint8_t *cls_in) {
   const int X = (int)volume->dims[0], Y = (int)volume->dims[1], Z = (int)volume->dims[2];
   const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 7) / 8;

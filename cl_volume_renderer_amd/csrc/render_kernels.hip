@@ -6,7 +6,7 @@
 // machine twice: only a fraction of the pixels hit anything, and the lanes that do walk paths of
 // very different lengths.  Here the pass is split where the divergence is:
 //
-//   k_repack   (when volume / SDF / TF changed)  packed bricked {value, sdf, class} records
+//   k_repack   (when volume / SDF / TF changed)  bricked step bytes + hit records (packed_volume.hpp)
 //   k_primary  (when the camera changed)         one lane per pixel: ray, box entry, primary march;
 //                                                hits are compacted into 64-byte records with a
 //                                                wave ballot + prefix (one atomic per wave);
@@ -22,6 +22,7 @@
 //   k_resolve  (when a frame is wanted)          read the accumulator AFTER the pass (deterministic;
 //                                                one legal outcome of the reference's race, SURVEY
 //                                                fact 4), tone curve, RGBA8
+//   k_ao       (shading = CLWH_SHADE_AO)         compute_ao (ray_marching.cl:104-149) per primary hit
 //
 // The primary march does not depend on the pass's seed, so its result is kept while camera, volume,
 // SDF and transfer function stay the same; per sample, every float operation is the one the reference

@@ -191,7 +191,7 @@ int clwh_accum_resolve(clwh_ctx *ctx, clwh_mem *accum_all_ranks, int32_t tile_wo
                        const float cam_dir[3]);
 /* drop what the context derived from its inputs; the next clwh_render rebuilds it.  Needed only when
  * device memory was rewritten behind the shim's back, or to time the rebuild.
- *   CLWH_DERIVED_SCENE   packed records (function of volume, SDF, transfer function: flush-time data)
+ *   CLWH_DERIVED_SCENE   step bytes + hit records (function of volume, SDF, transfer function: flush-time data)
  *   CLWH_DERIVED_CAMERA  primary hits (function of the camera and of the scene) */
 enum clwh_derived { CLWH_DERIVED_SCENE = 1, CLWH_DERIVED_CAMERA = 2 };
 int clwh_ctx_invalidate_derived(clwh_ctx *ctx, int what);
