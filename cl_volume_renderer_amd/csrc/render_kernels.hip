@@ -244,7 +244,12 @@ __global__ __launch_bounds__(256) void k_commit(const RenderArgs a) {
 constexpr int kFixupDwords = 32;  // one record = 128 B: header[4] bv_before[3] n_pending[1] 2 x {P[3] factor dir[3]}
 
 #ifndef CLVR_BOUNCE_WAVES_PER_SIMD
-#define CLVR_BOUNCE_WAVES_PER_SIMD 4  // register budget 128: no spills; measured 4 / 5 / 6 / 7 -> 24.2 / 24.0 / 23.2 / 17.2 Gsamples/s (profiles/r01_tune_occupancy_v7.txt)
+// Register budget 80 = six waves per SIMD.  Round 1 (86-92 VGPRs at the time) measured 4 / 5 / 6 / 7 -> 24.2 / 24.0 / 23.2 / 17.2
+// Gsamples/s; since the hit records the image-space kernel needs 80 registers by itself and the 64-pass launch does not care
+// (4 / 5 / 6 / 8 -> 29.08 / 29.26 / 29.07 / 15.6), while a single-pass launch -- one sample per resident lane, 5184 waves of
+// work -- fits in ONE generation of 6144 resident waves instead of 5120 + a second round: 0.285 -> 0.263 ms per pass (the
+// voxel-cache variants spill 7-9 registers for it and are still faster); tools/sweep_single_pass.sh.
+#define CLVR_BOUNCE_WAVES_PER_SIMD 6
 #endif
 template <bool USE_GRAD, int MODE, bool SMALL>
 __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(const RenderArgs a) {
