@@ -24,6 +24,9 @@ struct TfDev {
   int32_t uses_gradient;
   int32_t literal_gradient_taps;  // 1: always take the reference's 7-fetch step (test knob CLWH_TUNE_LITERAL_GRADIENT)
   int32_t opaque;                 // 1: classes come from a hiprtc-compiled is_event_gen (tf_jit.cpp); rules hold only colours
+  int32_t border_class;           // class of the border texel (value 0) for gradient-free rule tables: 1 + index of the first rule that
+                                  // contains 0, or 0.  read_imagei returns 0 outside the volume, and a position with a NaN coordinate
+                                  // or a coordinate == dimension is not 'exited' (utility_ray.cl:112-117): it classifies as value 0
   TfRuleDev rules[CLWH_TF_MAX_RULES];
 };
 

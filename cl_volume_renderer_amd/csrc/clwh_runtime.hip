@@ -55,6 +55,12 @@ static void tf_to_dev(const clwh_tf &tf, TfDev &d) {
               (((uint32_t)r.color[2] & 255u) << 16) | (((uint32_t)r.color[3] & 255u) << 24);
     if (r.use_gradient) d.uses_gradient = 1;
   }
+  // the border texel's class (see TfDev::border_class); tables that read `gradient` classify such positions literally
+  for (int k = 0; k < tf.n && !d.uses_gradient; ++k) {
+    const clwh_tf_rule &r = tf.rules[k];
+    if (r.v_lo <= 0 && 0 <= r.v_hi) { d.border_class = k + 1; break; }
+    if (r.terminal) break;
+  }
 }
 
 // ---- hiprtc fallback (tf_jit.cpp): compile once per source text and context

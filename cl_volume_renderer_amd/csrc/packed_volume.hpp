@@ -121,14 +121,13 @@ struct VolumePacked {
     if ((unsigned)x >= (unsigned)X || (unsigned)y >= (unsigned)Y || (unsigned)z >= (unsigned)Z) return 0u;
     return stepb[part_x<SMALL>((unsigned)x) + part_y<SMALL>((unsigned)y) + part_z<SMALL>((unsigned)z)];
   }
-  // The march's fetch after `!exited_volume(pos)`: every coordinate is then >= 0 (or -0.0), <= its dimension, or
-  // NaN.  trunc == floor for such values, so only `coordinate < dimension` remains to be tested (false for NaN
-  // and for coordinate == dimension, which both read the border), and the in-brick offset is formed in 32 bits
-  // so that the load can use scalar-base + 32-bit-offset addressing.  SMALL: the volume has fewer than 2^23
-  // bricks, every step byte has a 32-bit offset and the brick number is formed with 24-bit multiplies.
+  // The march's fetch at a position that HAS a voxel: classify_step has tested `coordinate < dimension` for all three
+  // (false for NaN and for coordinate == dimension, which read the border texel instead) after `!exited_volume(pos)`,
+  // so every coordinate is in [0, dimension) or -0.0 and trunc == floor.  The in-brick offset is formed in 32 bits so
+  // that the load can use scalar-base + 32-bit-offset addressing.  SMALL: the volume has fewer than 2^23 bricks, every
+  // step byte has a 32-bit offset and the brick number is formed with 24-bit multiplies.
   template <bool SMALL>
   __device__ __forceinline__ unsigned step_marched(float fx, float fy, float fz) const {
-    if (!(fx < (float)X && fy < (float)Y && fz < (float)Z)) return 0u;
     const unsigned ux = (unsigned)(int)fx, uy = (unsigned)(int)fy, uz = (unsigned)(int)fz;
     return stepb[part_x<SMALL>(ux) + part_y<SMALL>(uy) + part_z<SMALL>(uz)];
   }

@@ -211,7 +211,10 @@ __device__ __forceinline__ f3 hit_gradient_and_color(const VolumePacked &v, cons
 template <bool USE_GRAD, bool SMALL = false, bool DEFER_COLOR = false>
 __device__ __forceinline__ bool classify_step(const VolumePacked &v, const TfDev &tf, f3 pos, uint32_t &color, int &next_sd,
                                               bool *color_pending = nullptr) {
-  if (USE_GRAD && !tf.opaque && (tf.literal_gradient_taps || !taps_are_voxel_neighbours(pos))) {
+  // both callers have just tested !exited_volume(pos): every coordinate is >= 0 (or -0.0), <= its dimension, or NaN.
+  // `inside`: the position has a voxel; otherwise (coordinate == dimension, NaN) the reference reads the border texel 0
+  const bool inside = pos.x < (float)v.X && pos.y < (float)v.Y && pos.z < (float)v.Z;
+  if (USE_GRAD && !tf.opaque && (tf.literal_gradient_taps || !inside || !taps_are_voxel_neighbours(pos))) {
     // the reference's own seven fetches, from the caller's images (utility_ray.cl:126-138)
     const int value = v.value_at(pos.x, pos.y, pos.z);
     const int gradient = (int)(short)f2i(length3(gradient_literal(v, pos)));
@@ -219,7 +222,15 @@ __device__ __forceinline__ bool classify_step(const VolumePacked &v, const TfDev
     next_sd = sd > 0 ? sd : 0;
     return tf_eval(tf, value, gradient, color);
   }
-  const unsigned q = v.template step_marched<SMALL>(pos.x, pos.y, pos.z);  // both callers have just tested !exited_volume(pos)
+  if (!inside) {
+    // the border texel: value 0, SDF 0; a Hit when a rule contains 0 (its colour needs no memory access)
+    next_sd = 0;
+    if (tf.border_class == 0) return false;
+    const TfRuleDev &rule = tf.rules[tf.border_class - 1];
+    if (rule.flags & TF_WRITES_COLOR) color = rule.color;
+    return true;
+  }
+  const unsigned q = v.template step_marched<SMALL>(pos.x, pos.y, pos.z);
   next_sd = (int)(q & 0x7Fu);
   if (!(q & 0x80u)) return false;
   if (DEFER_COLOR) {

@@ -140,3 +140,21 @@ def test_extreme_voxel_values_fill_the_17_bit_hit_record_fields(gpu_ctx, orc):
     hits = _parity(orc, gpu_ctx, vol, env, tf, (96, 96), pos, d, scene.glibc_rand(3))
     assert hits > 2000
     _parity(orc, gpu_ctx, vol, env, tf, (96, 96), pos, d, [77], mode="image")
+
+
+def test_transfer_function_that_matches_the_border_value_zero(gpu_ctx, orc):
+    """read_imagei outside the volume returns the border value 0 (CLK_ADDRESS_CLAMP), and a position with a NaN
+    coordinate or with a coordinate exactly equal to the dimension is still 'inside' for exited_volume
+    (utility_ray.cl:112-117) -- so a transfer function whose value range contains 0 turns such a position into a Hit
+    on the border.  Piecewise-constant volume (zero gradients -> NaN normals -> NaN rays) with such a TF."""
+    rng = np.random.default_rng(123)
+    coarse = rng.choice(np.array([-1000, 700, 150, 1100, 40, -50], np.int16), size=(8, 8, 8))
+    vol = np.ascontiguousarray(np.kron(coarse, np.ones((6, 6, 6), np.int16)).astype(np.int16))
+    env = scene.env_map(64, 32)
+    tf = scene.tf_rect_source([(-100.0, 300.0, 0.0, 4000.0, (0.9, 0.6, 0.3, 0.7))])
+    pos, d = look_at_centre(vol, [-15, 30, -20])
+    hits = _parity(orc, gpu_ctx, vol, env, tf, (128, 96), pos, d, scene.glibc_rand(3))
+    assert hits > 3000
+    # the same with a rule that reads `gradient` (the literal 7-fetch route at irregular positions)
+    tf2 = scene.tf_rect_source([(-100.0, 300.0, -1.0, 3000.0, (0.9, 0.6, 0.3, 0.7))], stats=(-2000.0, 3000.0, 0.0, 4000.0))
+    _parity(orc, gpu_ctx, vol, env, tf2, (128, 96), pos, d, scene.glibc_rand(2))
