@@ -531,6 +531,7 @@ def main():
         "steps": K,
         "warmup": WU,
         "ms_per_step": round(elapsed * 1e3 / K, 4),
+        "timed_region_s": round(sum(region_s), 4),  # everything between the first and the last timing bracket of the headline value
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
