@@ -44,10 +44,14 @@ __device__ __forceinline__ bool tf_eval(const TfDev &tf, int value_in, int gradi
 // own neighbours unless an addition rounds across an integer (p.x = 255.99999 + 1 -> 257.0).  Such positions are
 // detected exactly and take the literal six taps from the caller's image; every other position inside the volume
 // reads the voxel's precomputed differences from its hit record: one 8-byte load, one line.
+// Only the +1 taps can be irregular.  Every caller passes a position inside the volume (0 <= p < dimension < 2^24, or
+// -0.0), and for such p the binary32 difference p - 1 always floors to floor(p) - 1: for p >= 2 it is exact (p - 1 stays a
+// multiple of ulp(p)), for 1 <= p < 2 it is exact by Sterbenz' lemma, and for 0 <= p < 1 it lies in [-1, -2^-24] whatever
+// the rounding, whose floor is -1.  p + 1 on the other hand rounds UP to the next integer when frac(p) is within half
+// an ulp of 1 (0.99999997 + 1 = 2.0).
 __device__ __forceinline__ bool taps_are_voxel_neighbours(f3 p) {
-  return floorf(p.x + 1.0f) == floorf(p.x) + 1.0f && floorf(p.x - 1.0f) == floorf(p.x) - 1.0f &&
-         floorf(p.y + 1.0f) == floorf(p.y) + 1.0f && floorf(p.y - 1.0f) == floorf(p.y) - 1.0f &&
-         floorf(p.z + 1.0f) == floorf(p.z) + 1.0f && floorf(p.z - 1.0f) == floorf(p.z) - 1.0f;
+  return floorf(p.x + 1.0f) == floorf(p.x) + 1.0f && floorf(p.y + 1.0f) == floorf(p.y) + 1.0f &&
+         floorf(p.z + 1.0f) == floorf(p.z) + 1.0f;
 }
 
 __device__ __forceinline__ f3 gradient_literal(const VolumePacked &v, f3 p) {
