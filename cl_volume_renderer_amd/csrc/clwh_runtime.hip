@@ -107,18 +107,19 @@ static int ensure_classes(clwh_ctx *ctx, const std::shared_ptr<JitTf> &jit, cons
     ctx->jit_cls_bytes = voxels;
   }
   constexpr int kColors = CLWH_TF_MAX_RULES;
-  if (!ctx->jit_palette) HIP_TRY(hipMalloc((void **)&ctx->jit_palette, (kColors + 1) * sizeof(unsigned long long)));
+  if (!ctx->jit_palette) HIP_TRY(hipMalloc((void **)&ctx->jit_palette, (kColors + 2) * sizeof(unsigned long long)));  // colours, error word, border class
   HIP_TRY(hipMemsetAsync(ctx->jit_palette, 0xFF, kColors * sizeof(unsigned long long), ctx->stream));
-  HIP_TRY(hipMemsetAsync(ctx->jit_palette + kColors, 0, sizeof(unsigned long long), ctx->stream));
+  HIP_TRY(hipMemsetAsync(ctx->jit_palette + kColors, 0, 2 * sizeof(unsigned long long), ctx->stream));
   const void *vol = volume->dptr;
   int X = (int)volume->dims[0], Y = (int)volume->dims[1], Z = (int)volume->dims[2], max_colors = kColors;
   unsigned char *cls = ctx->jit_cls;
   unsigned long long *palette = ctx->jit_palette;
   int *error = reinterpret_cast<int *>(ctx->jit_palette + kColors);
-  void *args[] = {&vol, &X, &Y, &Z, &cls, &palette, &max_colors, &error};
+  int *border = reinterpret_cast<int *>(ctx->jit_palette + kColors + 1);
+  void *args[] = {&vol, &X, &Y, &Z, &cls, &palette, &max_colors, &error, &border};
   const size_t blocks = std::min<size_t>((voxels + 255u) / 256u, (size_t)1u << 23);  // the classifier strides over the rest
   HIP_TRY(hipModuleLaunchKernel(jit->classify, (unsigned)blocks, 1, 1, 256, 1, 1, 0, ctx->stream, args, nullptr));
-  unsigned long long host[kColors + 1];
+  unsigned long long host[kColors + 2];
   HIP_TRY(hipMemcpyAsync(host, ctx->jit_palette, sizeof host, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   ctx->jit_vol = nullptr;  // invalid until fully built
@@ -131,6 +132,7 @@ static int ensure_classes(clwh_ctx *ctx, const std::shared_ptr<JitTf> &jit, cons
     t.rules[k].color = (uint32_t)(host[k] & 0xFFFFFFFFull);
     t.n = k + 1;
   }
+  t.border_class = (int32_t)(host[kColors + 1] & 0xFFull);  // is_event_gen(0, 0): the border texel (TfDev::border_class)
   ctx->jit_tf = t;
   ctx->jit_vol = volume->dptr;
   ctx->jit_vol_ver = volume->version;

@@ -30,9 +30,28 @@ static const char *kClassifier = R"(
 #undef inline
 #undef int4
 #undef uint4
+__device__ unsigned char clvr_tf_class_of(short value, short gradient, unsigned long long *palette, int max_colors, int *error) {
+  tf_int4 c = {-1, -1, -1, -1};
+  if (!is_event_gen(value, gradient, &c)) return 0;
+  const bool wrote = !(c.x == -1 && c.y == -1 && c.z == -1 && c.w == -1);
+  const unsigned long long key = wrote ? (0x100000000ull | (unsigned)(c.x & 255) | ((unsigned)(c.y & 255) << 8) |
+                                          ((unsigned)(c.z & 255) << 16) | ((unsigned)(c.w & 255) << 24))
+                                       : 0ull;
+  for (int k = 0; k < max_colors; ++k) {
+    const unsigned long long prev = atomicCAS(&palette[k], ~0ull, key);
+    if (prev == ~0ull || prev == key) return (unsigned char)(k + 1);
+  }
+  *error = 1;
+  return 0;
+}
+
+// `border_class` receives the class of the border texel: value 0 with gradient 0 (what a position with a NaN coordinate
+// reads; a position with a coordinate == dimension reads value 0 too, with whatever gradient its in-range taps give --
+// approximated by this class)
 extern "C" __global__ void clvr_tf_classify(const short *vol, int X, int Y, int Z, unsigned char *cls,
-                                            unsigned long long *palette, int max_colors, int *error) {
+                                            unsigned long long *palette, int max_colors, int *error, int *border_class) {
   const size_t n = (size_t)X * (size_t)Y * (size_t)Z;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *border_class = clvr_tf_class_of((short)0, (short)0, palette, max_colors, error);
   // grid-stride: a launch may not exceed 2^32 work-items (2048^3 voxels = 2^33)
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
   const int x = (int)(i % (size_t)X), y = (int)((i / (size_t)X) % (size_t)Y), z = (int)(i / ((size_t)X * (size_t)Y));
@@ -45,20 +64,7 @@ extern "C" __global__ void clvr_tf_classify(const short *vol, int X, int Y, int 
   const float gz = (float)(at(x, y, z + 1) - at(x, y, z - 1));
   float len = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)), __fmul_rn(gz, gz)));
   int gi = (len != len) ? 0 : (len >= 2147483648.0f ? 2147483647 : (int)len);
-  tf_int4 c = {-1, -1, -1, -1};
-  const bool e = is_event_gen((short)vol[i], (short)gi, &c);
-  unsigned char out = 0;
-  if (e) {
-    const bool wrote = !(c.x == -1 && c.y == -1 && c.z == -1 && c.w == -1);
-    const unsigned long long key = wrote ? (0x100000000ull | (unsigned)(c.x & 255) | ((unsigned)(c.y & 255) << 8) |
-                                            ((unsigned)(c.z & 255) << 16) | ((unsigned)(c.w & 255) << 24))
-                                         : 0ull;
-    for (int k = 0; k < max_colors; ++k) {
-      const unsigned long long prev = atomicCAS(&palette[k], ~0ull, key);
-      if (prev == ~0ull || prev == key) { out = (unsigned char)(k + 1); break; }
-    }
-    if (!out) *error = 1;
-  }
+  const unsigned char out = clvr_tf_class_of((short)vol[i], (short)gi, palette, max_colors, error);
   cls[i] = out;
   }
 }

@@ -158,3 +158,33 @@ def test_transfer_function_that_matches_the_border_value_zero(gpu_ctx, orc):
     # the same with a rule that reads `gradient` (the literal 7-fetch route at irregular positions)
     tf2 = scene.tf_rect_source([(-100.0, 300.0, -1.0, 3000.0, (0.9, 0.6, 0.3, 0.7))], stats=(-2000.0, 3000.0, 0.0, 4000.0))
     _parity(orc, gpu_ctx, vol, env, tf2, (128, 96), pos, d, scene.glibc_rand(2))
+
+
+def test_free_form_tf_that_matches_the_border_value(gpu_ctx, orc):
+    """the same border case through the hiprtc route: a free-form source (outside the rule grammar) whose event set
+    contains value 0; the compiled classifier also evaluates is_event_gen(0, 0) for the border texel."""
+    source = ("inline bool is_event_gen(short value, short gradient, int4 *color){\n"
+              "  int4 shade = {229, 153, 76, 178};\n"
+              "  if(value >= -100 && value <= 300 || value == 31000) { *color = shade; return true; }\n"
+              "  return false;\n}\n")
+    with pytest.raises(ffi.ClwhError):
+        ffi.parse_tf(source)
+    rules = orc.parse_tf(scene.tf_rect_source([(-100.0, 300.0, 0.0, 4000.0, (0.9, 0.6, 0.3, 0.7))]))
+    assert tuple(rules.rules[0].color) == (229, 153, 76, 178)
+    rng = np.random.default_rng(123)
+    coarse = rng.choice(np.array([-1000, 700, 150, 1100, 40, -50], np.int16), size=(8, 8, 8))
+    vol = np.ascontiguousarray(np.kron(coarse, np.ones((6, 6, 6), np.int16)).astype(np.int16))
+    env = scene.env_map(64, 32)
+    pos, d = look_at_centre(vol, [-15, 30, -20])
+    sdf, _, _ = orc.sdf_build(vol, rules)
+    g = GpuScene(gpu_ctx, vol, None, env, source, (128, 96))
+    gpu_ctx.sdf_build(g.volume, source, g.sdf)
+    assert np.array_equal(g.sdf.pull(), sdf)
+    o = orc.Scene(vol, sdf, env, rules, (128, 96))
+    for s in scene.glibc_rand(3):
+        g.render(pos, d, s)
+        o.render(pos, d, s)
+        assert np.array_equal(g.hit_index.pull(), o.hit_index)
+        assert np.array_equal(g.contrib.pull(), o.contrib)
+    assert np.array_equal(g.cache.pull(), o.cache)
+    g.release()
