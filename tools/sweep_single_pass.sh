@@ -1,3 +1,6 @@
+#!/bin/bash
+# tools/sweep_single_pass.sh -- on the GPU box: k_bounce's register budget (waves per SIMD) against the single-pass latency of the
+# reference's own call pattern (bench.py's reference_exact_mode / drop_in_path) and the headline value; restores the default build.
 for W in 4 5 6 8; do
   CLVR_EXTRA_HIPCC_FLAGS="-DCLVR_BOUNCE_WAVES_PER_SIMD=$W" python3 -m cl_volume_renderer_amd.build --force > /dev/null 2>&1
   python3 bench.py --no-cpu-baseline > gpurun_out/single_w$W.json 2> /dev/null

@@ -9,6 +9,7 @@ sys.path.insert(0, ".")
 from cl_volume_renderer_amd import ffi, scene  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+torch.cuda.init()  # torch's HIP runtime first (see tests/conftest.py)
 ctx = ffi.Context(0)
 vol = scene.phantom(n)
 v = ctx.image_from(vol)
