@@ -102,6 +102,13 @@ typedef struct {
   /* optional instrumentation of the bounce phase's march steps (tools/step_locality.py): */
   uint64_t *locality;         /* ORC_LOC_COUNT totals, accumulated; NULL = off */
   const uint8_t *uniform4;    /* optional, one byte per 4x4x4 sub-brick [z/4][y/4][x/4]: 1 = all 64 step bytes equal */
+  /* optional, for the same instrumentation: the "exit certificate" experiment (tools/exit_certificate.py).  One byte per
+   * macro cell of macro_m^3 voxels [z][y][x]: 0 = the cell (dilated by 2 voxels) holds an event voxel or a non-positive SDF
+   * value, else the smallest SDF value in it.  After a bounce-phase step whose next SDF value is >= cert_t the oracle walks the
+   * cells from the new position to the volume's boundary: all non-zero and few enough steps left => the march must end in
+   * Exit_volume without a Hit, and every later step of that march is counted as avoidable. */
+  const uint8_t *macro_free_min;
+  int32_t macro_m, cert_t;
 } orc_render_params;
 
 /* locality[]: where the step fetches of the distribution rays fall (every fetch of a step byte = one SDF texel read) */
@@ -119,13 +126,17 @@ enum {
   ORC_LOC_STEP_LE_8 = 10,
   ORC_LOC_STEP_LE_32 = 11,
   ORC_LOC_STEPS = 12,       /* march steps of the bounce phase */
+  ORC_LOC_CERT_TRIED = 13,  /* exit certificates attempted / granted; steps (= step-byte fetches) that followed a granted one */
+  ORC_LOC_CERT_GRANTED = 14,
+  ORC_LOC_CERT_SAVED = 15,
   ORC_LOC_COUNT = 16,
   /* followed, in the same array, by two histograms of march steps (the dependent chain a lane walks):
    * [ORC_LOC_HIST_RAY + n]  distribution rays with n steps (n clamped to 255; a ray is at most 3 marches = 210 steps)
    * [ORC_LOC_HIST_ITEM + n] samples (both distribution rays) with n steps (n clamped to 511) */
   ORC_LOC_HIST_RAY = 16,
   ORC_LOC_HIST_ITEM = 16 + 256,
-  ORC_LOC_TOTAL = 16 + 256 + 512
+  ORC_LOC_CERT_WRONG = 16 + 256 + 512, /* granted certificates whose march did NOT end in Exit_volume (must stay 0) */
+  ORC_LOC_TOTAL = 16 + 256 + 512 + 8
 };
 
 /* number of ushorts the voxel cache needs so that the reference's latent one-row overrun

@@ -18,9 +18,9 @@ _LIB_PATH = os.path.join(_HERE, "_build", "liborc.so")
 
 TF_MAX_RULES = 16
 N_COUNTERS = 12
-LOCALITY_TOTAL, LOCALITY_HIST_RAY, LOCALITY_HIST_ITEM = 16 + 256 + 512, 16, 16 + 256
+LOCALITY_TOTAL, LOCALITY_HIST_RAY, LOCALITY_HIST_ITEM, LOCALITY_CERT_WRONG = 16 + 256 + 512 + 8, 16, 16 + 256, 16 + 256 + 512
 LOCALITY_NAMES = ("fetches", "same_sub4", "same_brick8", "near_8", "near_16", "near_32", "near_64", "uniform4",
-                  "step_le_1", "step_le_2", "step_le_8", "step_le_32", "steps")
+                  "step_le_1", "step_le_2", "step_le_8", "step_le_32", "steps", "cert_tried", "cert_granted", "cert_saved")
 COUNTER_NAMES = ("n_sdf", "n_vol", "n_env", "n_tok", "n_add", "n_read", "n_hit", "n_step",
                  "n_sdf_primary", "n_vol_primary", "n_env_primary", "reserved")
 MODE_VOXEL_CACHE, MODE_IMAGE_SPACE = 0, 1
@@ -64,6 +64,7 @@ class RenderParams(C.Structure):
         ("threads", C.c_int32),
         ("shading", C.c_int32),
         ("locality", C.c_void_p), ("uniform4", C.c_void_p),
+        ("macro_free_min", C.c_void_p), ("macro_m", C.c_int32), ("cert_t", C.c_int32),
     ]
 
 
@@ -270,6 +271,7 @@ class Scene:
         self.tile_rank, self.tile_world, self.threads = tile_rank, tile_world, threads
         self.locality = None   # set to np.zeros(LOCALITY_TOTAL, uint64) to collect the bounce phase's step-locality counters
         self.uniform4 = None   # optional uint8 [ceil(Z/4)][ceil(Y/4)][ceil(X/4)] flags for the same instrumentation
+        self.macro_free_min, self.macro_m, self.cert_t = None, 0, 0   # exit-certificate experiment (orc.h)
 
     def _params(self, cam_pos, cam_dir, seed):
         X, Y, Z = self.dims
@@ -294,6 +296,8 @@ class Scene:
         p.shading = self.shading
         p.locality = self.locality.ctypes.data if self.locality is not None else None
         p.uniform4 = self.uniform4.ctypes.data if self.uniform4 is not None else None
+        p.macro_free_min = self.macro_free_min.ctypes.data if self.macro_free_min is not None else None
+        p.macro_m, p.cert_t = int(self.macro_m), int(self.cert_t)
         return p
 
     def render(self, cam_pos, cam_dir, seed):

@@ -306,14 +306,74 @@ static inline ray_t march(ctx_t *c, ray_t cur) {
   return r;
 }
 
+/* instrumentation only: can the march from `pos` along `d` be PROVEN to leave the volume without a Hit within `budget`
+ * steps, from the macro-cell table alone?  (3-D DDA over the cells, binary64) */
+static int certify_exit(const orc_render_params *p, f3 pos, f3 d, int budget) {
+  const double M = (double)p->macro_m;
+  const int nx = (p->X + p->macro_m - 1) / p->macro_m, ny = (p->Y + p->macro_m - 1) / p->macro_m,
+            nz = (p->Z + p->macro_m - 1) / p->macro_m;
+  const double o[3] = {pos.x, pos.y, pos.z}, dir[3] = {d.x, d.y, d.z}, dim[3] = {(double)p->X, (double)p->Y, (double)p->Z};
+  const int n[3] = {nx, ny, nz};
+  int cell[3], step[3];
+  double t_next[3], t_delta[3], t_exit = 1e30;
+  for (int k = 0; k < 3; ++k) {
+    if (!(o[k] >= 0.0 && o[k] <= dim[k]) || dir[k] != dir[k]) return 0;
+    cell[k] = (int)(o[k] / M);
+    if (cell[k] >= n[k]) cell[k] = n[k] - 1;
+    if (dir[k] > 0.0) {
+      step[k] = 1; t_delta[k] = M / dir[k]; t_next[k] = ((cell[k] + 1) * M - o[k]) / dir[k];
+      const double te = (dim[k] - o[k]) / dir[k];
+      if (te < t_exit) t_exit = te;
+    } else if (dir[k] < 0.0) {
+      step[k] = -1; t_delta[k] = -M / dir[k]; t_next[k] = (cell[k] * M - o[k]) / dir[k];
+      const double te = (0.0 - o[k]) / dir[k];
+      if (te < t_exit) t_exit = te;
+    } else {
+      step[k] = 0; t_delta[k] = 1e30; t_next[k] = 1e30;
+    }
+  }
+  if (!(t_exit < 1e29)) return 0;
+  int s_min = 127;
+  for (int guard = 0; guard < 4096; ++guard) {
+    const int fm = p->macro_free_min[((int64_t)cell[2] * ny + cell[1]) * nx + cell[0]];
+    if (fm == 0) return 0;
+    if (fm < s_min) s_min = fm;
+    int a = 0;
+    if (t_next[1] < t_next[a]) a = 1;
+    if (t_next[2] < t_next[a]) a = 2;
+    if (t_next[a] > t_exit + 2.0) break;  /* past the boundary (2 voxels of slack for the rounding of the real march) */
+    cell[a] += step[a];
+    if (cell[a] < 0 || cell[a] >= n[a]) break;
+    t_next[a] += t_delta[a];
+  }
+  /* every step of the march is at least s_min long: ceil(t_exit / s_min) + 2 steps certainly leave the volume */
+  return (int)(t_exit / (double)s_min) + 3 <= budget;
+}
+
 /* utility_ray.cl:157-168 march_to_next_event */
 static inline ray_t march_to_next_event(ctx_t *c, ray_t cur, int *event_type, i4 *value_at_event) {
   int internal_event = EV_NONE;
+  int certified = 0;  /* instrumentation only */
+  const int instrument = c->p->locality && c->p->macro_free_min && c->in_bounce;
   for (int i = 0; i < 70; ++i) {
     cur = march(c, cur);
+    if (certified) c->loc[ORC_LOC_CERT_SAVED]++;
     internal_event = get_event_and_value(c, cur.origin, value_at_event);
     if (internal_event != EV_NONE) break;
+    if (instrument && !certified) {
+      const orc_render_params *p = c->p;
+      const i4 q = make_int(cur.origin);
+      const int sd = in_range(p, q.x, q.y, q.z) ? p->sdf[lin(p, q.x, q.y, q.z)] : 0;
+      if (sd >= p->cert_t) {
+        c->loc[ORC_LOC_CERT_TRIED]++;
+        if (certify_exit(p, cur.origin, cur.direction, 70 - (i + 1))) {
+          certified = 1;
+          c->loc[ORC_LOC_CERT_GRANTED]++;
+        }
+      }
+    }
   }
+  if (certified && internal_event != EV_EXIT) c->loc[ORC_LOC_CERT_WRONG]++;
   *event_type = internal_event;
   return cur;
 }
