@@ -55,6 +55,11 @@ struct RenderArgs {
   const uint8_t *stepb;    // bricked per-step bytes (packed_volume.hpp)
   const int16_t *volume_lin;  // the caller's images (x fastest): literal taps of the rare paths
   const int8_t *sdf_lin;
+  // exit certificates (render_kernels.hip, certify_exit): eight bytes per macro cell of 16^3 voxels; byte o: a bound on the steps of a
+  // march from this cell in direction octant o until it leaves the volume, 255 = the box it crosses is not free
+  const uint8_t *macro;
+  int32_t MNX, MNY, MNZ;
+  int32_t cert_min_step;   // a march asks for a certificate once its next step is at least this long; 0 = certificates off
   int32_t NBX, NBY;
   const uint32_t *env;     // RGBA8 packed, row-major
   int32_t env_w, env_h;
@@ -103,6 +108,7 @@ struct RepackArgs {
   int32_t NBX, NBY, NBZ;
   uint2 *grec;
   uint8_t *stepb;
+  uint32_t *brick_min;     // per brick: 0 if a voxel may be an event or has a non-positive SDF value, else the smallest SDF value
   const uint8_t *cls_in;   // opaque TF: class byte per voxel (linear), computed by the JIT classifier
   TfDev tf;
 };
@@ -133,6 +139,7 @@ struct JitTf {
 
 // host-side launchers implemented in the .hip files
 hipError_t launch_repack(const RepackArgs &a, hipStream_t s);
+hipError_t launch_macro_table(const uint32_t *brick_min, int NBX, int NBY, int NBZ, uint8_t *macro, int MNX, int MNY, int MNZ, int X, int Y, int Z, hipStream_t s);
 hipError_t launch_primary(const RenderArgs &a, hipStream_t s);
 hipError_t launch_bounce(const RenderArgs &a, hipStream_t s);
 hipError_t launch_env_fixup(const RenderArgs &a, hipStream_t s);
@@ -204,6 +211,7 @@ struct clwh_ctx {
   int32_t tune_literal_gradient = 0;
   int32_t tune_unit_block_log2 = 4;
   int32_t tune_unit_group = 1, tune_unit_affinity = 0, tune_unit_queues = 8;
+  int32_t tune_cert_min_step = 32;  // CLWH_TUNE_CERT: 0 = exit certificates off
   uint32_t tune_bounce_max_blocks = 2048;
   bool primary_valid = false;
   uint32_t primary_n_hits = 0;
@@ -225,7 +233,7 @@ struct clwh_ctx {
   uint8_t *sdf_flags = nullptr;     // 4 x tiles bytes (current / next / being cleared / done)
   size_t sdf_flags_bytes = 0;
   // derived packed volume (single entry, keyed by the source objects' identity + version and the TF)
-  uint8_t *packed = nullptr;  // hit records (8 B per voxel of the brick grid), then the step bytes (1 B)
+  uint8_t *packed = nullptr;  // hit records (8 B per voxel of the brick grid), the step bytes (1 B), the per-brick minima (4 B per brick), the macro-cell table
   size_t packed_bytes = 0;
   const void *packed_vol = nullptr, *packed_sdf = nullptr;
   uint64_t packed_vol_ver = 0, packed_sdf_ver = 0;

@@ -171,6 +171,7 @@ int clwh_ctx_create_on_stream(int device, void *hip_stream, clwh_ctx **out) {
   if (const char *e = std::getenv("CLWH_TUNE_GROUP")) c->tune_unit_group = std::max(1, std::atoi(e));
   if (const char *e = std::getenv("CLWH_TUNE_CHUNK_BLOCK_LOG2")) c->tune_unit_block_log2 = std::max(0, std::min(8, std::atoi(e)));
   if (const char *e = std::getenv("CLWH_TUNE_BLOCKS")) c->tune_bounce_max_blocks = (uint32_t)std::max(1, std::atoi(e));
+  if (const char *e = std::getenv("CLWH_TUNE_CERT")) c->tune_cert_min_step = std::max(0, std::min(127, std::atoi(e)));
   *out = c;
   return CLWH_OK;
 }
@@ -524,7 +525,12 @@ static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *
   const int X = (int)volume->dims[0], Y = (int)volume->dims[1], Z = (int)volume->dims[2];
   const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 7) / 8;
   const size_t records = (size_t)NBX * NBY * NBZ * 512u;
-  const size_t bytes = records * (sizeof(uint2) + 1u);  // hit records, then the per-step bytes
+  const size_t n_bricks = (size_t)NBX * NBY * NBZ;
+  const int MNX = (X + 15) / 16, MNY = (Y + 15) / 16, MNZ = (Z + 15) / 16;  // macro cells of the exit certificates
+  // hit records, the per-step bytes, the per-brick minima (u32, 16-byte aligned), the macro-cell table
+  const size_t off_brick_min = (records * (sizeof(uint2) + 1u) + 15u) & ~(size_t)15u;
+  const size_t off_macro = (off_brick_min + n_bricks * sizeof(uint32_t) + 15u) & ~(size_t)15u;
+  const size_t bytes = off_macro + (size_t)MNX * MNY * MNZ * 8u;  // eight octant entries per cell
   if (ctx->packed_valid && ctx->packed_bytes == bytes && ctx->packed_vol == volume->dptr &&
       ctx->packed_sdf == sdf->dptr && ctx->packed_vol_ver == volume->version &&
       ctx->packed_sdf_ver == sdf->version && !std::memcmp(&ctx->packed_tf, &tf, sizeof tf))
@@ -548,6 +554,8 @@ static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *
   r.NBX = NBX; r.NBY = NBY; r.NBZ = NBZ;
   r.grec = reinterpret_cast<uint2 *>(ctx->packed);
   r.stepb = ctx->packed + records * sizeof(uint2);
+  r.brick_min = reinterpret_cast<uint32_t *>(ctx->packed + off_brick_min);
+  HIP_TRY(hipMemsetAsync(r.brick_min, 0xFF, n_bricks * sizeof(uint32_t), ctx->stream));
   r.cls_in = cls_in;
   r.tf = tf;
   {
@@ -555,6 +563,7 @@ static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *
     int trc = t.begin(ctx, CLWH_TIMER_REPACK);
     if (trc != CLWH_OK) return trc;
     HIP_TRY(launch_repack(r, ctx->stream));
+    HIP_TRY(launch_macro_table(r.brick_min, NBX, NBY, NBZ, ctx->packed + off_macro, MNX, MNY, MNZ, X, Y, Z, ctx->stream));
     trc = t.end();
     if (trc != CLWH_OK) return trc;
   }
@@ -691,6 +700,18 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   a.stepb = ctx->packed + (size_t)a.NBX * a.NBY * ((a.Z + 7) / 8) * 512u * sizeof(uint2);
   a.volume_lin = (const int16_t *)d->volume->dptr;
   a.sdf_lin = (const int8_t *)d->sdf->dptr;
+  {
+    const size_t records = (size_t)a.NBX * a.NBY * ((a.Z + 7) / 8) * 512u, n_bricks = records / 512u;
+    const size_t off_brick_min = (records * (sizeof(uint2) + 1u) + 15u) & ~(size_t)15u;
+    a.macro = ctx->packed + ((off_brick_min + n_bricks * sizeof(uint32_t) + 15u) & ~(size_t)15u);
+    a.MNX = (a.X + 15) / 16; a.MNY = (a.Y + 15) / 16; a.MNZ = (a.Z + 15) / 16;
+    // An exit certificate proves "this march leaves the volume without a Hit"; a position with a coordinate == dimension or NaN
+    // reads the border texel (value 0), so tables under which value 0 can be an event keep marching literally.
+    bool zero_may_hit = a.tf.border_class != 0;
+    for (int q = 0; q < a.tf.n && a.tf.uses_gradient && !a.tf.opaque; ++q)
+      if (a.tf.rules[q].v_lo <= 0 && 0 <= a.tf.rules[q].v_hi) zero_may_hit = true;
+    a.cert_min_step = zero_may_hit ? 0 : ctx->tune_cert_min_step;
+  }
 
   // ---- primary hits of this camera: rebuilt only when something they depend on changed
   const size_t slots = (size_t)a.num_tile_slots * 64u;
@@ -791,13 +812,14 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     if (rc != CLWH_OK) return rc;
 #ifdef CLVR_BOUNCE_STATS  // experiment builds only (CLVR_EXTRA_HIPCC_FLAGS=-DCLVR_BOUNCE_STATS): scheduling statistics of the launch
     {
-      uint32_t h[18];
+      uint32_t h[21];
       HIP_TRY(hipMemcpyAsync(h, ctx->render_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       std::fprintf(stderr, "[bounce stats] items=%llu step_iters=%u avg_march_lanes=%.2f event_phases=%u avg_event_lanes=%.2f "
-                   "refills=%u avg_refill=%.2f events start/exit/hit/none=%u/%u/%u/%u\n",
+                   "refills=%u avg_refill=%.2f events start/exit/hit/none=%u/%u/%u/%u cert_phases=%u avg_cert_lanes=%.2f cert_granted=%u\n",
                    (unsigned long long)h[0] * (unsigned long long)a.n_seeds, h[8], h[8] ? (double)h[9] / h[8] : 0.0, h[10],
-                   h[10] ? (double)h[11] / h[10] : 0.0, h[12], h[12] ? (double)h[13] / h[12] : 0.0, h[14], h[15], h[16], h[17]);
+                   h[10] ? (double)h[11] / h[10] : 0.0, h[12], h[12] ? (double)h[13] / h[12] : 0.0, h[14], h[15], h[16], h[17], h[18],
+                   h[18] ? (double)h[19] / h[18] : 0.0, h[20]);
     }
 #endif
     TimedLaunch tf;

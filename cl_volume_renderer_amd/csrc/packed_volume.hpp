@@ -36,6 +36,9 @@ struct VolumePacked {
   const int8_t *__restrict__ sdf_lin;
   int X, Y, Z;
   int NBX, NBY;  // bricks per row / per slice
+  // SMALL == 2 only: the three per-axis index terms as tables in LDS (part_x below), y's and z's after x's
+  const uint32_t *parts = nullptr;
+  int parts_y0 = 0, parts_z0 = 0;
 
   // offset of a voxel inside its 8x8x8 brick
   __host__ __device__ static inline unsigned inner_index(unsigned ux, unsigned uy, unsigned uz) {
@@ -62,28 +65,38 @@ struct VolumePacked {
   }
 
   // The brick index is separable: index(x, y, z) = part_x(x) + part_y(y) + part_z(z) -- the brick number is a sum
-  // of per-axis terms and the in-brick bit fields of the three axes are disjoint.  SMALL (fewer than 2^23 bricks):
-  // parts are 32-bit and use full-rate 24-bit multiply-adds (the compiler turns __umul24 back into quarter-rate
-  // 32/64-bit multiplies).
-  template <bool SMALL> struct Index { using type = size_t; };
+  // of per-axis terms and the in-brick bit fields of the three axes are disjoint.  SMALL != 0 (fewer than 2^23
+  // bricks): parts are 32-bit and use full-rate 24-bit multiply-adds (the compiler turns __umul24 back into
+  // quarter-rate 32/64-bit multiplies).  SMALL == 2: the parts come from tables in LDS -- three ds_read_b32 and
+  // their three address instructions replace some twenty VALU instructions per index, in a kernel that is bound by
+  // VALU issue (k_bounce fills the tables; kPartsMaxEntries bounds X + Y + Z).
+  static constexpr int kPartsMaxEntries = 6144;
+  template <int SMALL> struct Index { using type = size_t; };
   __device__ __forceinline__ static unsigned mul24_uniform(unsigned v, int uniform) {
     unsigned r;
     asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(v), "s"(uniform));
     return r;
   }
-  template <bool SMALL>
+  template <int SMALL>
   __device__ __forceinline__ typename Index<SMALL>::type part_x(unsigned u) const {
-    return ((typename Index<SMALL>::type)(u >> 3) << 9) | inner_index(u, 0u, 0u);
+    if constexpr (SMALL == 2) return parts[u];
+    else return ((typename Index<SMALL>::type)(u >> 3) << 9) | inner_index(u, 0u, 0u);
   }
-  template <bool SMALL>
+  template <int SMALL>
   __device__ __forceinline__ typename Index<SMALL>::type part_y(unsigned u) const {
-    const unsigned b = SMALL ? mul24_uniform(u >> 3, NBX) : (u >> 3) * (unsigned)NBX;
-    return ((typename Index<SMALL>::type)b << 9) | inner_index(0u, u, 0u);
+    if constexpr (SMALL == 2) return parts[(unsigned)parts_y0 + u];
+    else {
+      const unsigned b = SMALL ? mul24_uniform(u >> 3, NBX) : (u >> 3) * (unsigned)NBX;
+      return ((typename Index<SMALL>::type)b << 9) | inner_index(0u, u, 0u);
+    }
   }
-  template <bool SMALL>
+  template <int SMALL>
   __device__ __forceinline__ typename Index<SMALL>::type part_z(unsigned u) const {
-    const unsigned b = SMALL ? mul24_uniform(u >> 3, NBX * NBY) : (u >> 3) * (unsigned)(NBX * NBY);
-    return ((typename Index<SMALL>::type)b << 9) | inner_index(0u, 0u, u);
+    if constexpr (SMALL == 2) return parts[(unsigned)parts_z0 + u];
+    else {
+      const unsigned b = SMALL ? mul24_uniform(u >> 3, NBX * NBY) : (u >> 3) * (unsigned)(NBX * NBY);
+      return ((typename Index<SMALL>::type)b << 9) | inner_index(0u, 0u, u);
+    }
   }
 
   // coordinates are non-negative and in range; the brick number fits 32 bits for every volume that
@@ -109,14 +122,14 @@ struct VolumePacked {
   }
 
   // the hit record of the voxel at floor(pos); the caller guarantees 0 <= coordinate < dimension
-  template <bool SMALL = false>
+  template <int SMALL = 0>
   __device__ __forceinline__ uint2 hit_record(float fx, float fy, float fz) const {
     const unsigned ux = (unsigned)(int)fx, uy = (unsigned)(int)fy, uz = (unsigned)(int)fz;
     return grec[part_x<SMALL>(ux) + part_y<SMALL>(uy) + part_z<SMALL>(uz)];
   }
 
   // the march's per-step byte: one 128-byte line holds two 4x4x4 sub-bricks, the whole 512^3 array is 128 MiB
-  template <bool SMALL = false>
+  template <int SMALL = 0>
   __device__ __forceinline__ unsigned step_i(int x, int y, int z) const {
     if ((unsigned)x >= (unsigned)X || (unsigned)y >= (unsigned)Y || (unsigned)z >= (unsigned)Z) return 0u;
     return stepb[part_x<SMALL>((unsigned)x) + part_y<SMALL>((unsigned)y) + part_z<SMALL>((unsigned)z)];
@@ -126,12 +139,13 @@ struct VolumePacked {
   // so every coordinate is in [0, dimension) or -0.0 and trunc == floor.  The in-brick offset is formed in 32 bits so
   // that the load can use scalar-base + 32-bit-offset addressing.  SMALL: the volume has fewer than 2^23 bricks, every
   // step byte has a 32-bit offset and the brick number is formed with 24-bit multiplies.
-  template <bool SMALL>
+  template <int SMALL>
   __device__ __forceinline__ unsigned step_marched(float fx, float fy, float fz) const {
     const unsigned ux = (unsigned)(int)fx, uy = (unsigned)(int)fy, uz = (unsigned)(int)fz;
     return stepb[part_x<SMALL>(ux) + part_y<SMALL>(uy) + part_z<SMALL>(uz)];
   }
 };
-template <> struct VolumePacked::Index<true> { using type = uint32_t; };
+template <> struct VolumePacked::Index<1> { using type = uint32_t; };
+template <> struct VolumePacked::Index<2> { using type = uint32_t; };
 
 }  // namespace clvr

@@ -67,7 +67,7 @@ __device__ __forceinline__ bool hit_record_serves(const VolumePacked &v, f3 p) {
   return inside && taps_are_voxel_neighbours(p);
 }
 
-template <bool SMALL = false>
+template <int SMALL = 0>
 __device__ __forceinline__ f3 gradient_nn(const VolumePacked &v, f3 p) {
   if (hit_record_serves(v, p)) {
     int gx, gy, gz;
@@ -179,7 +179,7 @@ __device__ __forceinline__ bool exited_volume(const Vol &v, f3 q) {
 // positions whose taps are not the voxel's neighbours (taps_are_voxel_neighbours above) take the literal 7-fetch route.
 
 // the colour of a Hit found through the step byte: the voxel's class (in its hit record) names the transfer-function rule
-template <bool SMALL = false>
+template <int SMALL = 0>
 __device__ __forceinline__ void hit_color(const VolumePacked &v, const TfDev &tf, f3 pos, uint32_t &color) {
   const unsigned cls = VolumePacked::hit_class(v.template hit_record<SMALL>(pos.x, pos.y, pos.z));  // a step-byte Hit is inside the volume
   const TfRuleDev &rule = tf.rules[cls - 1u];
@@ -188,7 +188,7 @@ __device__ __forceinline__ void hit_color(const VolumePacked &v, const TfDev &tf
 
 // what a Hit needs from memory in ONE 8-byte load: the rule colour (when `want_color`, i.e. the Hit was found through the
 // step byte and its colour is still pending) and the gradient for the normal
-template <bool SMALL = false>
+template <int SMALL = 0>
 __device__ __forceinline__ f3 hit_gradient_and_color(const VolumePacked &v, const TfDev &tf, f3 pos, bool want_color, uint32_t &color) {
   const bool regular = hit_record_serves(v, pos);
   if (regular || want_color) {
@@ -212,7 +212,7 @@ __device__ __forceinline__ f3 hit_gradient_and_color(const VolumePacked &v, cons
 // for the rule's colour -- the persistent bounce kernel does that in its event phase together with the normal's gradient
 // (hit_gradient_and_color), where it costs one pass per event phase rather than one per march iteration in which any
 // lane happens to hit.
-template <bool USE_GRAD, bool SMALL = false, bool DEFER_COLOR = false>
+template <bool USE_GRAD, int SMALL = 0, bool DEFER_COLOR = false>
 __device__ __forceinline__ bool classify_step(const VolumePacked &v, const TfDev &tf, f3 pos, uint32_t &color, int &next_sd,
                                               bool *color_pending = nullptr) {
   // both callers have just tested !exited_volume(pos): every coordinate is >= 0 (or -0.0), <= its dimension, or NaN.

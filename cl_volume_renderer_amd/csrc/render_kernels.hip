@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
     const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
     uint2 r = uint2{0u, 0u};
     uint8_t q = 0u;
+    uint32_t free_min = 255u;  // for the exit certificates: 0 = this voxel may be an event / has no positive SDF value
     if (x < a.X && y < a.Y && z < a.Z) {
       const int value = s_val[lz + 1][ly + 1][lx + 1];
       const int sd = s_sdf[lz][ly][lx];
@@ -120,20 +121,114 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
       }
       // class = 1 + index of the first matching rule; a terminal rule (`return (cond);`) ends the evaluation
       unsigned cls = a.cls_in ? a.cls_in[((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x] : 0u;
+      // `maybe`: could this voxel be an event for SOME gradient?  (A rule that reads `gradient` is evaluated literally, with
+      // other taps, at the rare positions whose +-1 taps are not the voxel's neighbours: its value window alone decides here.)
+      bool maybe = cls != 0u;
       for (int k = 0; k < a.tf.n && !a.cls_in; ++k) {
         const TfRuleDev &rule = a.tf.rules[k];
         bool m = value >= rule.v_lo && value <= rule.v_hi;
+        maybe = maybe || m;
         if (rule.flags & TF_USE_GRADIENT) m = m && gradient >= rule.g_lo && gradient <= rule.g_hi;
-        if (m) { cls = (unsigned)k + 1u; break; }
-        if (rule.flags & TF_TERMINAL) break;
+        if (m && cls == 0u) cls = (unsigned)k + 1u;
+        if (m || (rule.flags & TF_TERMINAL)) break;
       }
       r = VolumePacked::pack_hit(dx, dy, dz, cls);
       q = (uint8_t)((cls ? 0x80u : 0u) | (uint32_t)(sd > 0 ? sd : 0));
+      free_min = (maybe || sd <= 0) ? 0u : (uint32_t)sd;
     }
     const size_t out = ((brick_row + (size_t)bx) << 9) + sub * 64u + lane;
     a.grec[out] = r;
     a.stepb[out] = q;
+    for (int off = 32; off > 0; off >>= 1) free_min = min(free_min, (uint32_t)__shfl_xor((int)free_min, off));
+    if (lane == 0u) atomicMin(&a.brick_min[brick_row + (size_t)bx], free_min);  // eight sub-bricks per brick
   }
+}
+
+// Exit-certificate table (certify_exit below).  One entry per macro cell of 16^3 voxels and direction octant o
+// (o = [d.x < 0] | [d.y < 0] << 1 | [d.z < 0] << 2): a march that starts anywhere in the cell with a direction of that
+// octant stays in the box between the cell and the volume corner the octant heads for.  The entry is an upper bound of
+// the number of steps such a march takes until it leaves the volume, or 255 if the box is not free.
+// Step 1: m = the smallest "free value" over the cell's bricks AND the bricks around them (a dilation by a whole brick:
+// the real march is off the ideal line by its roundings) -- 0 if a voxel there may be an event or has an SDF value below
+// kCertMinStep, else the smallest SDF value; all eight octant entries start as m.
+constexpr uint32_t kCertMinStep = 2u;
+#ifndef CLVR_CERT_PHASE_MIN_LANES
+#define CLVR_CERT_PHASE_MIN_LANES 16
+#endif
+constexpr int kCertPhaseMinLanes = CLVR_CERT_PHASE_MIN_LANES;  // certificates are looked up once this many lanes of a wave wait for one
+__global__ __launch_bounds__(256) void k_macro_table(const uint32_t *__restrict__ brick_min, int NBX, int NBY, int NBZ,
+                                                     uint2 *__restrict__ macro, int MNX, int MNY, int MNZ) {
+  const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (c >= MNX * MNY * MNZ) return;
+  const int cx = c % MNX, cy = (c / MNX) % MNY, cz = c / (MNX * MNY);
+  uint32_t m = 255u;
+  for (int bz = max(cz * 2 - 1, 0); bz <= min(cz * 2 + 2, NBZ - 1); ++bz)
+    for (int by = max(cy * 2 - 1, 0); by <= min(cy * 2 + 2, NBY - 1); ++by)
+      for (int bx = max(cx * 2 - 1, 0); bx <= min(cx * 2 + 2, NBX - 1); ++bx)
+        m = min(m, brick_min[((size_t)bz * (size_t)NBY + (size_t)by) * (size_t)NBX + (size_t)bx]);
+  if (m < kCertMinStep) m = 0u;
+  m *= 0x01010101u;
+  macro[c] = make_uint2(m, m);
+}
+
+// per-byte minimum of two packed octant entries
+__device__ __forceinline__ uint2 min_bytes(uint2 a, uint2 b) {
+  uint2 r;
+  r.x = r.y = 0u;
+  for (int k = 0; k < 32; k += 8) {
+    r.x |= min((a.x >> k) & 0xFFu, (b.x >> k) & 0xFFu) << k;
+    r.y |= min((a.y >> k) & 0xFFu, (b.y >> k) & 0xFFu) << k;
+  }
+  return r;
+}
+// Step 2, once per axis: octant entry o of a cell becomes the minimum over the cells from here to the end of the line in
+// o's direction along this axis -- after the three passes, the minimum over the whole box.  One thread per line.
+__global__ __launch_bounds__(64) void k_macro_octants(uint2 *__restrict__ macro, int MNX, int MNY, int MNZ, int axis) {
+  const int n[3] = {MNX, MNY, MNZ};
+  const int len = n[axis], u_n = n[(axis + 1) % 3], v_n = n[(axis + 2) % 3];
+  const int line = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (line >= u_n * v_n) return;
+  int c[3];
+  c[(axis + 1) % 3] = line % u_n;
+  c[(axis + 2) % 3] = line / u_n;
+  // bytes of the octants that run towards coordinate 0 on this axis (octant o is byte o of the 8-byte entry)
+  const uint2 neg = axis == 0 ? make_uint2(0xFF00FF00u, 0xFF00FF00u) : (axis == 1 ? make_uint2(0xFFFF0000u, 0xFFFF0000u) : make_uint2(0u, 0xFFFFFFFFu));
+  auto at = [&](int i) -> uint2 & {
+    c[axis] = i;
+    return macro[((size_t)c[2] * (size_t)MNY + (size_t)c[1]) * (size_t)MNX + (size_t)c[0]];
+  };
+  uint2 run = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  for (int i = len - 1; i >= 0; --i) {  // positive direction: accumulate from the far end backwards
+    const uint2 v = at(i);
+    run = min_bytes(run, v);
+    at(i) = make_uint2((v.x & neg.x) | (run.x & ~neg.x), (v.y & neg.y) | (run.y & ~neg.y));
+  }
+  run = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  for (int i = 0; i < len; ++i) {  // negative direction: from coordinate 0 forwards
+    const uint2 v = at(i);
+    run = min_bytes(run, v);
+    at(i) = make_uint2((v.x & ~neg.x) | (run.x & neg.x), (v.y & ~neg.y) | (run.y & neg.y));
+  }
+}
+// Step 3: box minimum -> step bound.  The longest path inside the box is its diagonal (a unit direction with
+// t = e.x / |d.x| = e.y / |d.y| = e.z / |d.z| has t = |e|), every step there is max(sdf, 0.5) >= the box minimum long, so
+// diagonal / minimum steps leave the volume; + 5 covers the roundings of this bound and of the march.
+__global__ __launch_bounds__(256) void k_macro_bounds(uint2 *__restrict__ macro, int MNX, int MNY, int MNZ, int X, int Y, int Z) {
+  const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (c >= MNX * MNY * MNZ) return;
+  const int cx = c % MNX, cy = (c / MNX) % MNY, cz = c / (MNX * MNY);
+  const uint2 v = macro[c];
+  uint2 r = make_uint2(0u, 0u);
+  for (int o = 0; o < 8; ++o) {
+    const uint32_t m = ((o < 4 ? v.x : v.y) >> ((o & 3) * 8)) & 0xFFu;
+    const float ex = (o & 1) ? (float)(cx * 16 + 16) : (float)(X - cx * 16);
+    const float ey = (o & 2) ? (float)(cy * 16 + 16) : (float)(Y - cy * 16);
+    const float ez = (o & 4) ? (float)(cz * 16 + 16) : (float)(Z - cz * 16);
+    uint32_t steps = 255u;
+    if (m != 0u) steps = (uint32_t)fminf(sqrtf(ex * ex + ey * ey + ez * ez) / (float)m + 5.0f, 255.0f);
+    if (o < 4) r.x |= steps << (o * 8); else r.y |= steps << ((o - 4) * 8);
+  }
+  macro[c] = r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -214,7 +309,7 @@ __global__ __launch_bounds__(64) void k_primary(const RenderArgs a) {
 // Lane state machine.  MARCH lanes take march steps; a lane that reaches an event (Hit / Exit /
 // 70 steps, or a freshly fetched item) parks in EVENT until the wave runs its event phase; IDLE
 // lanes have no item.
-enum : int { ST_IDLE = 0, ST_MARCH = 1, ST_EVENT = 2 };
+enum : int { ST_IDLE = 0, ST_MARCH = 1, ST_EVENT = 2, ST_CERT = 3 };  // CERT: parked for an exit-certificate attempt
 enum : int { EV_START = 3,              // a freshly fetched item: start distribution ray 1
              EV_HIT_COLOR_PENDING = 4 };  // a Hit whose rule colour is still to be fetched (classify_step DEFER_COLOR)
 
@@ -263,21 +358,56 @@ __global__ __launch_bounds__(256) void k_commit(const RenderArgs a) {
 // the reference's order.  Every sample is accumulated exactly once, by one of the two kernels.
 constexpr int kFixupDwords = 32;  // one record = 128 B: header[4] bv_before[3] n_pending[1] 2 x {P[3] factor dir[3]}
 
+// ------------------------------------------------------------------------------------------------
+// Exit certificates.  A march that ends in Exit_volume contributes through its DIRECTION only (ray_marching.cl:54-62
+// samples the environment with current_ray.direction): where it leaves the volume is never used.  So when it can be
+// PROVEN that a march will leave the volume without a Hit within the steps it has left, its remaining steps -- far-field
+// fetches, one 128-byte line each, for a position nobody needs -- are skipped and the Exit event is raised at once; the
+// result is bit-identical.  The proof is one table lookup: the ray's coordinates are monotone, so the rest of its path
+// lies in the box between its macro cell (16^3 voxels) and the volume corner its direction octant heads for, and the
+// table (k_macro_table .. k_macro_bounds) holds, per cell and octant, a bound on the steps of ANY such march if that
+// box, dilated by a brick, is free: no voxel that could be an event (a Hit needs one) and SDF values of at least
+// kCertMinStep.  The bound must fit the march's budget (a march that ran out of steps would continue as the NEXT march,
+// with another weight, ray_marching.cl:52-73).  tools/exit_certificate.py measured the idea on the oracle first: every
+// exiting ray gets its certificate at some point, 5 of the 30 step fetches per item disappear (all far field), and not
+// one certificate in millions was wrong.
+__device__ __forceinline__ bool certify_exit(const RenderArgs &a, f3 p, f3 d, int budget) {
+  // the position has a voxel or sits on the far face: 0 <= p <= dim (or -0.0)
+  const unsigned cx = min((unsigned)(int)p.x >> 4, (unsigned)a.MNX - 1u), cy = min((unsigned)(int)p.y >> 4, (unsigned)a.MNY - 1u),
+                 cz = min((unsigned)(int)p.z >> 4, (unsigned)a.MNZ - 1u);
+  const unsigned octant = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+  const int bound = a.macro[((((size_t)cz * (size_t)a.MNY + (size_t)cy) * (size_t)a.MNX + (size_t)cx) << 3) | octant];
+  const float dsum = d.x + d.y + d.z;  // NaN direction: the position turns NaN and never leaves
+  return bound <= budget && dsum == dsum;
+}
+
 #ifndef CLVR_BOUNCE_WAVES_PER_SIMD
-// Register budget 80 = six waves per SIMD.  Round 1 (86-92 VGPRs at the time) measured 4 / 5 / 6 / 7 -> 24.2 / 24.0 / 23.2 / 17.2
-// Gsamples/s; since the hit records the image-space kernel needs 80 registers by itself and the 64-pass launch does not care
-// (4 / 5 / 6 / 8 -> 29.08 / 29.26 / 29.07 / 15.6), while a single-pass launch -- one sample per resident lane, 5184 waves of
-// work -- fits in ONE generation of 6144 resident waves instead of 5120 + a second round: 0.285 -> 0.263 ms per pass (the
-// voxel-cache variants spill 7-9 registers for it and are still faster); tools/sweep_single_pass.sh.
-#define CLVR_BOUNCE_WAVES_PER_SIMD 6
+// Waves per SIMD.  With the event-only state in LDS (`cold` below) every variant of the kernel needs 64 registers or fewer, so
+// the register file allows eight; LDS (22 KB per 256-thread block at 512^3: the cold state, the index tables, div255) allows seven
+// blocks per CU.  Measured on the 64-pass launch, 6 / 7 / 8 (8 with 512-thread blocks) -> 4.27 / 4.14 / 4.22 ms
+// (profiles/r02_sweep_k_bounce_lds_state.txt); before that change the kernel held 80 registers + 9 spilled and ran six.
+#define CLVR_BOUNCE_WAVES_PER_SIMD 7
 #endif
-template <bool USE_GRAD, int MODE, bool SMALL>
-__global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(const RenderArgs a) {
-  const VolumePacked vol = make_volume(a);
+#ifndef CLVR_BOUNCE_THREADS
+#define CLVR_BOUNCE_THREADS 256
+#endif
+constexpr int kBounceThreads = CLVR_BOUNCE_THREADS;  // the waves of a block share the LDS index tables
+template <bool USE_GRAD, int MODE, bool SMALL_VOLUME>
+__global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(const RenderArgs a) {
+  constexpr int SMALL = SMALL_VOLUME ? 2 : 0;  // 2: the per-axis index terms are read from LDS (packed_volume.hpp)
+  VolumePacked vol = make_volume(a);
+  extern __shared__ uint32_t lds_parts[];
+  if (SMALL == 2) {
+    vol.parts = lds_parts;
+    vol.parts_y0 = a.X;
+    vol.parts_z0 = a.X + a.Y;
+    for (int k = (int)threadIdx.x; k < a.X + a.Y + a.Z; k += kBounceThreads)
+      lds_parts[k] = k < a.X ? vol.part_x<1>((unsigned)k) : (k < a.X + a.Y ? vol.part_y<1>((unsigned)(k - a.X)) : vol.part_z<1>((unsigned)(k - a.X - a.Y)));
+  }
   // c / 255.0f for the 256 possible colour bytes (a correctly rounded division is ~10 VALU instructions, the
   // kernel is VALU-issue bound, and every bounce needs four of them): one LDS read instead
   __shared__ float div255[256];
-  div255[threadIdx.x] = (float)threadIdx.x / 255.0f;
+  if (threadIdx.x < 256u) div255[threadIdx.x] = (float)threadIdx.x / 255.0f;
   __syncthreads();
   // counters: [0] hits, [2] fix-up records, [32 * (q + 1)] head of unit queue q (the overflow flag lives in sticky_flags)
   // the hit count of this camera: a kernel argument, or still only on the device (single-pass launches, clwh_render)
@@ -286,31 +416,36 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
   const unsigned lane = lane_id();
   // HW_REG_XCC_ID (id 20), bits [3:0]: the XCD this wave runs on
   unsigned home_queue = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
-  if (a.unit_affinity == 1) home_queue = (blockIdx.x * 4u + (threadIdx.x >> 6)) & 7u;
+  if (a.unit_affinity == 1) home_queue = (blockIdx.x * (unsigned)(kBounceThreads / 64) + (threadIdx.x >> 6)) & 7u;
   if (a.unit_affinity == 2) home_queue = 0u;
   unsigned queue_dry = 0u;  // bit q: queue q is known to be empty (lane 0's copy is the one that matters)
-  int fix = -1;    // fix-up record of the lane's sample (-1: none, -2: dropped, the buffer overflowed)
-  int npend = 0;   // pending environment terms written to it
-
-  // the sample
-  uint32_t gx = 0, gy = 0, hit = 0;  // global pixel, hit index
-  int seed = 0;
-  int64_t entry = -1;
-  f3 hit_origin{0, 0, 0}, hit_direction{0, 0, 0}, normal{0, 0, 0};  // hit_information + its normal
+  // The sample.  What only the event phase needs lives in LDS, one dword per lane and field (a conflict-free
+  // ds_read/ds_write each): the registers decide how many waves a SIMD holds, and with one dependent fetch per step it
+  // is the number of waves in flight that sets the pace.
+  enum : int { C_START_X, C_START_Y, C_START_Z,  // hit origin + hit direction: where both distribution rays start from
+               C_NORMAL_X, C_NORMAL_Y, C_NORMAL_Z,
+               C_ENTRY_LO, C_ENTRY_HI, C_PIXEL, C_HIT, C_SEED,
+               C_FIX,  // (fix + 2) << 2 | npend; fix: fix-up record of the sample (-1: none, -2: dropped, the buffer overflowed),
+                       // npend: pending environment terms written to it
+               C_BV_R, C_BV_G, C_BV_B, C_FIELDS };
+  __shared__ uint32_t cold[C_FIELDS][kBounceThreads];
+#define COLD(f) cold[f][threadIdx.x]
   // path state; energies and colour carry over from distribution ray 1 into ray 2 (SURVEY "hard parts")
   Ray ray{{0, 0, 0}, {0, 0, 0}};
   float atten = 0.0f, r_energy = 0.0f, g_energy = 0.0f, b_energy = 0.0f;
-  uint32_t color = 0u, bv_r = 0u, bv_g = 0u, bv_b = 0u;
+  uint32_t color = 0u;
   int o = 0, i = 0;
   // scheduling state
   int st = ST_IDLE;
   int ev = EV_NONE;        // pending event of an EVENT lane
   int sd = 0;              // SDF value for the next step of a MARCH lane
   int steps_left = 0;
+  int cert_at = 0;         // the lane asks for an exit certificate once its next step is at least this long (0: never)
   bool exhausted = false;  // wave-uniform: the queue has no more items
 #ifdef CLVR_BOUNCE_STATS
   uint32_t st_step_iters = 0, st_step_lanes = 0, st_event_phases = 0, st_event_lanes = 0, st_refills = 0, st_refill_lanes = 0;
   uint32_t st_ev_kind[4] = {0, 0, 0, 0};
+  uint32_t st_cert_phases = 0, st_cert_lanes = 0, st_cert_granted = 0;
 #endif
 
   for (;;) {
@@ -370,31 +505,32 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
           const uint32_t chunk = ((q_sel + NQ * (ch >> KB)) << KB) + (ch & ((1u << KB) - 1u));
           const uint32_t h = chunk * 64u + (item & 63u);
           if (h < n_hits) {
-            fix = -1;
-            npend = 0;
             const uint4 *src = reinterpret_cast<const uint4 *>(&a.hits[h]);
             const uint4 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3];
-            hit_origin = f3{__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
-            hit_direction = f3{__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
-            normal = f3{__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(q2.x)};
+            const f3 hit_origin = f3{__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
+            const f3 hit_direction = f3{__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
+            const f3 start = hit_origin + hit_direction;  // ray_bounce_fake_reflectance's origin (utility_ray.cl:100-103)
             color = q2.y;
-            entry = (int64_t)(((uint64_t)q2.w << 32) | (uint64_t)q2.z);
-            gx = q3.x & 0xFFFFu;
-            gy = q3.x >> 16;
-            hit = h;
-            seed = a.seeds[s];
+            const int64_t entry = (int64_t)(((uint64_t)q2.w << 32) | (uint64_t)q2.z);
             bool granted = true;
             if (MODE == CLWH_ACCUM_VOXEL_CACHE) granted = entry >= 0 && cache_take_token(a.cache, entry, 256u);
             if (granted) {
+              COLD(C_START_X) = __float_as_uint(start.x); COLD(C_START_Y) = __float_as_uint(start.y); COLD(C_START_Z) = __float_as_uint(start.z);
+              COLD(C_NORMAL_X) = q1.z; COLD(C_NORMAL_Y) = q1.w; COLD(C_NORMAL_Z) = q2.x;
+              COLD(C_ENTRY_LO) = q2.z; COLD(C_ENTRY_HI) = q2.w;
+              COLD(C_PIXEL) = q3.x;
+              COLD(C_HIT) = h;
+              COLD(C_SEED) = (uint32_t)a.seeds[s];
+              COLD(C_FIX) = (uint32_t)(-1 + 2) << 2;
+              COLD(C_BV_R) = 0u; COLD(C_BV_G) = 0u; COLD(C_BV_B) = 0u;
               r_energy = div255[color & 255u];
               g_energy = div255[(color >> 8) & 255u];
               b_energy = div255[(color >> 16) & 255u];
-              bv_r = bv_g = bv_b = 0u;
               o = 1;
               st = ST_EVENT;
               ev = EV_START;
             } else if (a.contrib_out) {
-              uint32_t *q = a.contrib_out + ((size_t)gy * (size_t)a.launch_w + gx) * 4;
+              uint32_t *q = a.contrib_out + ((size_t)(q3.x >> 16) * (size_t)a.launch_w + (q3.x & 0xFFFFu)) * 4;
               q[0] = 0u; q[1] = 0u; q[2] = 0u; q[3] = 0u;
             }
           }
@@ -408,6 +544,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
         atomicAdd(&a.counters[10], st_event_phases); atomicAdd(&a.counters[11], st_event_lanes);
         atomicAdd(&a.counters[12], st_refills); atomicAdd(&a.counters[13], st_refill_lanes);
         for (int k = 0; k < 4; ++k) atomicAdd(&a.counters[14 + k], st_ev_kind[k]);
+        atomicAdd(&a.counters[18], st_cert_phases); atomicAdd(&a.counters[19], st_cert_lanes); atomicAdd(&a.counters[20], st_cert_granted);
       }
 #endif
       if (exhausted) break;  // nothing in flight and nothing left to fetch
@@ -439,8 +576,31 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
               st = ST_EVENT;
             } else {
               sd = next_sd;
+              if (cert_at != 0 && sd >= cert_at) st = ST_CERT;  // far from every surface: can the rest of this march be proven to exit?
             }
           }
+        }
+        // ---- exit certificates, inside the step loop: lanes park until enough of them wait (or nobody marches), one table
+        // lookup each (certify_exit), and go back to marching or on to their Exit event; the loop, and with it the lane
+        // count of the event phase, is the same as without certificates
+        const int n_cert = __popcll(__ballot(st == ST_CERT));
+        if (n_cert != 0 && (n_cert >= kCertPhaseMinLanes || __popcll(__ballot(st == ST_MARCH)) < a.step_min_lanes)) {
+#ifdef CLVR_BOUNCE_STATS
+          st_cert_phases += 1; st_cert_lanes += (uint32_t)n_cert;
+          const int marching_before = __popcll(__ballot(st == ST_MARCH));
+#endif
+          if (st == ST_CERT) {
+            if (certify_exit(a, ray.origin, ray.direction, steps_left)) {
+              ev = EV_EXIT;       // the march WOULD end in Exit_volume; only its direction matters from here on
+              st = ST_EVENT;
+            } else {
+              cert_at = sd >= 64 ? 0 : max(2 * sd, cert_at);  // try again when the ray is twice as far from everything
+              st = ST_MARCH;
+            }
+          }
+#ifdef CLVR_BOUNCE_STATS
+          st_cert_granted += (uint32_t)(n_cert - (__popcll(__ballot(st == ST_MARCH)) - marching_before));
+#endif
         }
       } while (__popcll(__ballot(st == ST_MARCH)) >= a.step_min_lanes);
     }
@@ -456,9 +616,8 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
     if (st == ST_EVENT) {
       bool start_path = (ev == EV_START);  // begin distribution ray `o` from the primary hit
       bool bounce = false, from_hit = false;
-      f3 bn = normal;
-      Ray bbase{hit_origin, hit_direction};
-      int bseed = 0;
+      f3 bn{0, 0, 0}, bstart{0, 0, 0};  // the bounce's normal and its origin + direction
+      int bseed = 0;                    // its seed, less the sample's
 
       if (ev == EV_EXIT) {
         // ray_marching.cl:54-62: left the volume -> environment light ends this distribution ray
@@ -466,12 +625,14 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
         const float factor = i == 8 ? 8.0f / 8.0f : (i == 9 ? 8.0f / 9.0f : (i == 10 ? 8.0f / 10.0f : 8.0f / (float)i));
         const float p_r = atten * r_energy, p_g = atten * g_energy, p_b = atten * b_energy;
         uint32_t light = 0u;
+        const uint32_t fix_word = COLD(C_FIX);
+        int fix = (int)(fix_word >> 2) - 2, npend = (int)(fix_word & 3u);
         bool certain = (fix == -1) && sample_environment_map_fast(a.env, a.env_w, a.env_h, ray.direction, light);
         if (certain) {
           // uint += float: promote, add, truncate back
-          bv_r = f2u((float)bv_r + p_r * (float)(light & 255u) * factor / 1.0f);
-          bv_g = f2u((float)bv_g + p_g * (float)((light >> 8) & 255u) * factor / 1.0f);
-          bv_b = f2u((float)bv_b + p_b * (float)((light >> 16) & 255u) * factor / 1.0f);
+          COLD(C_BV_R) = f2u((float)COLD(C_BV_R) + p_r * (float)(light & 255u) * factor / 1.0f);
+          COLD(C_BV_G) = f2u((float)COLD(C_BV_G) + p_g * (float)((light >> 8) & 255u) * factor / 1.0f);
+          COLD(C_BV_B) = f2u((float)COLD(C_BV_B) + p_b * (float)((light >> 16) & 255u) * factor / 1.0f);
         } else {
           if (fix == -1) {
             // first undecided lookup of this sample: open a fix-up record
@@ -479,11 +640,11 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
             if (slot < a.fixup_capacity) {
               fix = (int)slot;
               uint32_t *rec = a.fixups + (size_t)slot * kFixupDwords;
-              rec[0] = hit;
-              rec[1] = (uint32_t)((uint64_t)entry & 0xFFFFFFFFull);
-              rec[2] = (uint32_t)((uint64_t)entry >> 32);
-              rec[3] = gx | (gy << 16);
-              rec[4] = bv_r; rec[5] = bv_g; rec[6] = bv_b;
+              rec[0] = COLD(C_HIT);
+              rec[1] = COLD(C_ENTRY_LO);
+              rec[2] = COLD(C_ENTRY_HI);
+              rec[3] = COLD(C_PIXEL);
+              rec[4] = COLD(C_BV_R); rec[5] = COLD(C_BV_G); rec[6] = COLD(C_BV_B);
             } else {
               a.sticky_flags[0] = 1u;  // reported by the host as an error; the sample is dropped
               fix = -2;
@@ -497,6 +658,7 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
             e[6] = __float_as_uint(ray.direction.z);
             npend += 1;
           }
+          COLD(C_FIX) = ((uint32_t)(fix + 2) << 2) | (uint32_t)npend;
         }
         o += 1;
         start_path = true;
@@ -504,8 +666,8 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
         // ray_marching.cl:63-72: secondary hit -> bounce around the local normal, attenuate; the rule colour (still
         // pending when the Hit came through the step byte) and the gradient arrive in one 8-byte load
         bn = -normalize3(hit_gradient_and_color<SMALL>(vol, a.tf, ray.origin, ev == EV_HIT_COLOR_PENDING, color));
-        bbase = ray;
-        bseed = seed + o + i;
+        bstart = ray.origin + ray.direction;
+        bseed = o + i;
         bounce = true;
         from_hit = true;
         i += 1;
@@ -530,14 +692,17 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
 
       if (start_path) {
         if (o > 2) {
-          if (fix == -1) finish_item<MODE>(a, entry, hit, gx, gy, bv_r, bv_g, bv_b);
-          else if (fix >= 0) a.fixups[(size_t)fix * kFixupDwords + 7] = (uint32_t)npend;  // k_env_fixup finishes it
+          const int fix = (int)(COLD(C_FIX) >> 2) - 2;
+          if (fix == -1)
+            finish_item<MODE>(a, (int64_t)(((uint64_t)COLD(C_ENTRY_HI) << 32) | (uint64_t)COLD(C_ENTRY_LO)), COLD(C_HIT), COLD(C_PIXEL) & 0xFFFFu,
+                              COLD(C_PIXEL) >> 16, COLD(C_BV_R), COLD(C_BV_G), COLD(C_BV_B));
+          else if (fix >= 0) a.fixups[(size_t)fix * kFixupDwords + 7] = COLD(C_FIX) & 3u;  // k_env_fixup finishes it
           st = ST_IDLE;
         } else {
           // ray_marching.cl:48: bounce from the primary hit around the primary normal
-          bn = normal;
-          bbase = Ray{hit_origin, hit_direction};
-          bseed = seed + o;
+          bn = f3{__uint_as_float(COLD(C_NORMAL_X)), __uint_as_float(COLD(C_NORMAL_Y)), __uint_as_float(COLD(C_NORMAL_Z))};
+          bstart = f3{__uint_as_float(COLD(C_START_X)), __uint_as_float(COLD(C_START_Y)), __uint_as_float(COLD(C_START_Z))};
+          bseed = o;
           bounce = true;
           from_hit = false;
         }
@@ -546,10 +711,10 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
       if (bounce) {
         // ray_bounce_fake_reflectance, then origin += normal*2 (ray_marching.cl:48-50 / :65-67)
         const float roughness = div255[color >> 24];
+        const uint32_t pixel = COLD(C_PIXEL);
         Ray nr;
-        nr.origin = bbase.origin + bbase.direction;
-        nr.direction = hemisphere_reflective(gx, gy, bn, bseed, roughness);
-        nr.origin = nr.origin + bn * 2.0f;
+        nr.direction = hemisphere_reflective(pixel & 0xFFFFu, pixel >> 16, bn, (int)COLD(C_SEED) + bseed, roughness);
+        nr.origin = bstart + bn * 2.0f;
         const float d = fabsf(dot3(nr.direction, bn));
         if (from_hit) {
           atten *= d;
@@ -567,10 +732,12 @@ __global__ __launch_bounds__(256, CLVR_BOUNCE_WAVES_PER_SIMD) void k_bounce(cons
         // start (or continue) a march: its first SDF read is at trunc(origin) (utility_ray.cl:148-150)
         sd = (int)(vol.template step_i<SMALL>(f2i(ray.origin.x), f2i(ray.origin.y), f2i(ray.origin.z)) & 0x7Fu);
         steps_left = 70;
+        cert_at = a.cert_min_step;
         st = ST_MARCH;
       }
     }
   }
+#undef COLD
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -726,6 +893,17 @@ hipError_t launch_repack(const RepackArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
+hipError_t launch_macro_table(const uint32_t *brick_min, int NBX, int NBY, int NBZ, uint8_t *macro8, int MNX, int MNY, int MNZ, int X, int Y, int Z, hipStream_t s) {
+  uint2 *macro = reinterpret_cast<uint2 *>(macro8);
+  const unsigned n = (unsigned)(MNX * MNY * MNZ);
+  hipLaunchKernelGGL(k_macro_table, dim3((n + 255u) / 256u), dim3(256), 0, s, brick_min, NBX, NBY, NBZ, macro, MNX, MNY, MNZ);
+  const int lines[3] = {MNY * MNZ, MNZ * MNX, MNX * MNY};
+  for (int axis = 0; axis < 3; ++axis)
+    hipLaunchKernelGGL(k_macro_octants, dim3(((unsigned)lines[axis] + 63u) / 64u), dim3(64), 0, s, macro, MNX, MNY, MNZ, axis);
+  hipLaunchKernelGGL(k_macro_bounds, dim3((n + 255u) / 256u), dim3(256), 0, s, macro, MNX, MNY, MNZ, X, Y, Z);
+  return hipGetLastError();
+}
+
 hipError_t launch_primary(const RenderArgs &a, hipStream_t s) {
   if (a.tf.uses_gradient)
     hipLaunchKernelGGL(k_primary<true>, dim3(a.num_tile_slots), dim3(64), 0, s, a);
@@ -740,24 +918,28 @@ hipError_t launch_bounce(const RenderArgs &a_in, hipStream_t s) {
   if (total == 0) return hipSuccess;
   // persistent grid: enough waves to fill the chip (256 CUs x 32 waves), never more than the work
   const uint64_t waves_needed = (total + 63u) / 64u;
-  const unsigned blocks = (unsigned)std::min<uint64_t>((waves_needed + 3u) / 4u, (uint64_t)a.bounce_max_blocks);
-  const dim3 grid(blocks), block(256);
+  constexpr unsigned wpb = (unsigned)kBounceThreads / 64u;  // waves per block; bounce_max_blocks counts 256-thread blocks
+  const unsigned blocks = (unsigned)std::min<uint64_t>((waves_needed + wpb - 1u) / wpb, ((uint64_t)a.bounce_max_blocks * 4u + wpb - 1u) / wpb);
+  const dim3 grid(blocks), block(kBounceThreads);
   // Scheduling thresholds (0 = automatic).  A launch with only a few units per wave (one or a few passes) is
   // bound by its longest dependent chain: every wave steps its samples to completion and refills when empty.
   // A long launch is bound by VALU issue: lanes refill at 16 idle and the march phase ends at 16 marching lanes.
   // Measured crossover on the headline scene: between 4 and 8 passes per launch = about 6 units per wave
   // (profiles/r01_tune_refill_step_thresholds.txt).
   // (with the hit count still on the device n_hits is the pixel count, an upper bound: such launches are single-pass)
-  const bool long_launch = !a.n_hits_on_device && waves_needed >= 6u * (uint64_t)blocks * 4u;
+  const bool long_launch = !a.n_hits_on_device && waves_needed >= 6u * (uint64_t)blocks * wpb;
   if (a.step_min_lanes <= 0) a.step_min_lanes = long_launch ? 16 : 1;
   if (a.refill_min_lanes <= 0) a.refill_min_lanes = long_launch ? 16 : 64;
   if ((uint64_t)(((a.n_hits + 63u) >> 6) + 8u * (1u << a.unit_block_log2)) * (uint64_t)a.n_seeds >= (1ull << 24)) return hipErrorInvalidValue;  // udivmod24
   const bool g = a.tf.uses_gradient != 0;
-  // fewer than 2^23 bricks (up to ~1600^3): every step byte has a 32-bit offset -> the march's 32-bit addressing
-  const bool small = (uint64_t)a.NBX * (uint64_t)a.NBY * (uint64_t)((a.Z + 7) / 8) < (1ull << 23);
+  // fewer than 2^23 bricks (up to ~1600^3): every step byte has a 32-bit offset -> the march's 32-bit addressing, with
+  // the index terms of the three axes in LDS tables
+  const bool small = (uint64_t)a.NBX * (uint64_t)a.NBY * (uint64_t)((a.Z + 7) / 8) < (1ull << 23) &&
+                     a.X + a.Y + a.Z <= VolumePacked::kPartsMaxEntries;
+  const size_t lds_parts_bytes = small ? (size_t)(a.X + a.Y + a.Z) * sizeof(uint32_t) : 0u;
 #define CLVR_LAUNCH_BOUNCE(G, M)                                                                    \
   do {                                                                                              \
-    if (small) hipLaunchKernelGGL((k_bounce<G, M, true>), grid, block, 0, s, a);                   \
+    if (small) hipLaunchKernelGGL((k_bounce<G, M, true>), grid, block, lds_parts_bytes, s, a);     \
     else hipLaunchKernelGGL((k_bounce<G, M, false>), grid, block, 0, s, a);                        \
   } while (0)
   if (a.mode == CLWH_ACCUM_VOXEL_CACHE) {

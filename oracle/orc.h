@@ -109,6 +109,11 @@ typedef struct {
    * Exit_volume without a Hit, and every later step of that march is counted as avoidable. */
   const uint8_t *macro_free_min;
   int32_t macro_m, cert_t;
+  int32_t cert_mode;          /* 0: walk the cells the ray crosses; 1: every cell of the box spanned by the ray's cell and its exit cell;
+                                 2: every cell of the octant region from the ray's cell to the volume corner it heads for;
+                                 3: as 2, the step count bounded by the region's diagonal / its smallest SDF value (no exit distance:
+                                    what k_bounce's table holds); 4: as 2, bounded by exit distance / the region's smallest SDF value */
+  int32_t cert_min_free;      /* modes 1-4: a cell counts as free only if its smallest SDF value is at least this */
 } orc_render_params;
 
 /* locality[]: where the step fetches of the distribution rays fall (every fetch of a step byte = one SDF texel read) */

@@ -65,6 +65,7 @@ class RenderParams(C.Structure):
         ("shading", C.c_int32),
         ("locality", C.c_void_p), ("uniform4", C.c_void_p),
         ("macro_free_min", C.c_void_p), ("macro_m", C.c_int32), ("cert_t", C.c_int32),
+        ("cert_mode", C.c_int32), ("cert_min_free", C.c_int32),
     ]
 
 
@@ -272,6 +273,7 @@ class Scene:
         self.locality = None   # set to np.zeros(LOCALITY_TOTAL, uint64) to collect the bounce phase's step-locality counters
         self.uniform4 = None   # optional uint8 [ceil(Z/4)][ceil(Y/4)][ceil(X/4)] flags for the same instrumentation
         self.macro_free_min, self.macro_m, self.cert_t = None, 0, 0   # exit-certificate experiment (orc.h)
+        self.cert_mode, self.cert_min_free = 0, 1
 
     def _params(self, cam_pos, cam_dir, seed):
         X, Y, Z = self.dims
@@ -298,6 +300,7 @@ class Scene:
         p.uniform4 = self.uniform4.ctypes.data if self.uniform4 is not None else None
         p.macro_free_min = self.macro_free_min.ctypes.data if self.macro_free_min is not None else None
         p.macro_m, p.cert_t = int(self.macro_m), int(self.cert_t)
+        p.cert_mode, p.cert_min_free = int(self.cert_mode), int(self.cert_min_free)
         return p
 
     def render(self, cam_pos, cam_dir, seed):

@@ -333,6 +333,42 @@ static int certify_exit(const orc_render_params *p, f3 pos, f3 d, int budget) {
     }
   }
   if (!(t_exit < 1e29)) return 0;
+  if (p->cert_mode != 0) {
+    /* box / octant variants: no walk, a block of cells must be free with SDF values >= cert_min_free */
+    int lo[3], hi[3];
+    for (int k = 0; k < 3; ++k) {
+      int far_cell;
+      if (p->cert_mode >= 2) far_cell = dir[k] > 0.0 ? n[k] - 1 : (dir[k] < 0.0 ? 0 : cell[k]);
+      else {
+        double e = o[k] + (t_exit + 2.0) * dir[k];
+        far_cell = (int)(e / M);
+        if (e < 0.0) far_cell = 0;
+        if (far_cell >= n[k]) far_cell = n[k] - 1;
+      }
+      lo[k] = cell[k] < far_cell ? cell[k] : far_cell;
+      hi[k] = cell[k] < far_cell ? far_cell : cell[k];
+    }
+    int region_min = 127;
+    for (int z = lo[2]; z <= hi[2]; ++z)
+      for (int y = lo[1]; y <= hi[1]; ++y)
+        for (int x = lo[0]; x <= hi[0]; ++x) {
+          const int fm = p->macro_free_min[((int64_t)z * ny + y) * nx + x];
+          if (fm < p->cert_min_free) return 0;
+          if (fm < region_min) region_min = fm;
+        }
+    if (p->cert_mode == 3) {
+      /* no t_exit: the longest path inside the box between the cell and the corner is its diagonal, every step is at least
+       * region_min long; mode 4: the same with the step count compared against a fixed budget (a table bit) */
+      double diag2 = 0.0;
+      for (int k = 0; k < 3; ++k) {
+        const double e = dir[k] > 0.0 ? dim[k] - cell[k] * M : (dir[k] < 0.0 ? (cell[k] + 1) * M : 0.0);
+        diag2 += e * e;
+      }
+      return (int)(sqrt(diag2) / (double)region_min) + 4 <= budget;
+    }
+    if (p->cert_mode == 4) return (int)(t_exit / (double)region_min) + 4 <= budget;
+    return (int)(t_exit / (double)p->cert_min_free) + 3 <= budget;
+  }
   int s_min = 127;
   for (int guard = 0; guard < 4096; ++guard) {
     const int fm = p->macro_free_min[((int64_t)cell[2] * ny + cell[1]) * nx + cell[0]];

@@ -18,6 +18,7 @@ from oracle import orc_ffi  # noqa: E402
 args = sys.argv[1:]
 n = int(args[0]) if args and args[0].isdigit() else 256
 cache = args[args.index("--sdf-cache") + 1] if "--sdf-cache" in args else None
+variants = "--variants" in args  # compare the cheaper proofs (one table lookup instead of a walk over the cells)
 w, h = (1920, 1080) if n >= 512 else (960, 544)
 vol = scene.phantom(n)
 tf = orc_ffi.parse_tf(scene.tf_default_source())
@@ -42,6 +43,29 @@ def macro_table(m, margin=2):
                 out[cz, cy, cx] = val[z0:z1, y0:y1, x0:x1].min()
     return out
 
+
+def report(sc, label):
+    L = dict(zip(orc_ffi.LOCALITY_NAMES, (int(v) for v in sc.locality)))
+    items = sc.counter_dict()["n_hit"]
+    print("%s: %.2f tries, %.2f granted per item; %.2f of the %.2f step fetches per item avoided (%.1f %%); wrong certificates: %d" % (
+        label, L["cert_tried"] / items, L["cert_granted"] / items, L["cert_saved"] / items, L["steps"] / items,
+        100.0 * L["cert_saved"] / L["steps"], int(sc.locality[orc_ffi.LOCALITY_CERT_WRONG])), flush=True)
+
+
+if variants:
+    # what k_bounce builds: cells of 16^3 voxels dilated by a brick; mode 0 walks the cells the ray crosses (a 3-D DDA), mode 2
+    # asks for the whole box between the cell and the volume corner of the direction's octant to be free and bounds the steps by
+    # t_exit / min_free, mode 3 bounds them by the box's diagonal / its smallest SDF value (no t_exit: ONE table lookup)
+    print("scene: phantom(%d), %dx%d, default camera, default TF, 1 pass; cells of 16^3 voxels dilated by 8" % (n, w, h))
+    table = macro_table(16, margin=8)
+    for mode, min_free, name in ((0, 1, "walk"), (2, 4, "octant box, t_exit / 4"), (3, 2, "octant box, diagonal / box minimum")):
+        for t in (8, 16, 32):
+            sc = orc_ffi.Scene(vol, sdf, env, tf, (w, h), mode=orc_ffi.MODE_IMAGE_SPACE, threads=len(os.sched_getaffinity(0)))
+            sc.locality = np.zeros(orc_ffi.LOCALITY_TOTAL, np.uint64)
+            sc.macro_free_min, sc.macro_m, sc.cert_t, sc.cert_mode, sc.cert_min_free = table, 16, t, mode, min_free
+            sc.render(pos, d, scene.glibc_rand(1)[0])
+            report(sc, "%-36s tried at every step >= %2d" % (name, t))
+    sys.exit(0)
 
 print("scene: phantom(%d), %dx%d, default camera, default TF, 2 passes" % (n, w, h))
 for m in (64, 32, 16):

@@ -14,6 +14,7 @@ while read -r SET; do
   rocprofv3 --pmc $SET --output-format csv -d "$OUT/p$i" -- $BENCH > /dev/null 2> "$OUT/p$i.err" || { tail -5 "$OUT/p$i.err"; exit 1; }
 done <<'SETS'
 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VALU
+SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM
 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INST_CYCLES_VMEM_RD SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32
 SETS
 python3 - "$OUT" <<'PY'
