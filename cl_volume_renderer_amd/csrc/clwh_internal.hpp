@@ -211,7 +211,7 @@ struct clwh_ctx {
   int32_t tune_literal_gradient = 0;
   int32_t tune_unit_block_log2 = 4;
   int32_t tune_unit_group = 1, tune_unit_affinity = 0, tune_unit_queues = 8;
-  int32_t tune_cert_min_step = 32;  // CLWH_TUNE_CERT: 0 = exit certificates off
+  int32_t tune_cert_min_step = 16;  // CLWH_TUNE_CERT: 0 = exit certificates off
   uint32_t tune_bounce_max_blocks = 2048;
   bool primary_valid = false;
   uint32_t primary_n_hits = 0;

@@ -309,9 +309,13 @@ __global__ __launch_bounds__(64) void k_primary(const RenderArgs a) {
 // Lane state machine.  MARCH lanes take march steps; a lane that reaches an event (Hit / Exit /
 // 70 steps, or a freshly fetched item) parks in EVENT until the wave runs its event phase; IDLE
 // lanes have no item.
-enum : int { ST_IDLE = 0, ST_MARCH = 1, ST_EVENT = 2, ST_CERT = 3 };  // CERT: parked for an exit-certificate attempt
+// One register holds both: ST_IDLE, ST_MARCH, ST_CERT (parked for an exit-certificate attempt), or ST_EVENT + the pending event.
+enum : int { ST_IDLE = 0, ST_MARCH = 1, ST_CERT = 2, ST_EVENT = 8 };
 enum : int { EV_START = 3,              // a freshly fetched item: start distribution ray 1
-             EV_HIT_COLOR_PENDING = 4 };  // a Hit whose rule colour is still to be fetched (classify_step DEFER_COLOR)
+             EV_HIT_COLOR_PENDING = 4,  // a Hit whose rule colour is still to be fetched (classify_step DEFER_COLOR)
+             EV_CHECK = 5,              // the new position has no voxel: left the volume, or one of the rare in-between cases?
+             EV_RESUMED = 6 };          // (inside the event phase only) it was one of those and the march goes on
+constexpr int kCertNever = 255;         // no step is this long
 
 // Image-space accumulation of one launch: a sample adds r | g<<16 | b<<32 | 1<<48 to its HIT's 64-bit
 // delta with ONE atomic (a launch has at most 64 seeds and a contribution is at most 255, so no field can
@@ -436,11 +440,10 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
   uint32_t color = 0u;
   int o = 0, i = 0;
   // scheduling state
-  int st = ST_IDLE;
-  int ev = EV_NONE;        // pending event of an EVENT lane
+  int st = ST_IDLE;        // ST_IDLE / ST_MARCH / ST_CERT / ST_EVENT + event
   int sd = 0;              // SDF value for the next step of a MARCH lane
   int steps_left = 0;
-  int cert_at = 0;         // the lane asks for an exit certificate once its next step is at least this long (0: never)
+  int cert_at = kCertNever;  // the lane asks for an exit certificate once its next step is at least this long
   bool exhausted = false;  // wave-uniform: the queue has no more items
 #ifdef CLVR_BOUNCE_STATS
   uint32_t st_step_iters = 0, st_step_lanes = 0, st_event_phases = 0, st_event_lanes = 0, st_refills = 0, st_refill_lanes = 0;
@@ -527,8 +530,7 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
               g_energy = div255[(color >> 8) & 255u];
               b_energy = div255[(color >> 16) & 255u];
               o = 1;
-              st = ST_EVENT;
-              ev = EV_START;
+              st = ST_EVENT + EV_START;
             } else if (a.contrib_out) {
               uint32_t *q = a.contrib_out + ((size_t)(q3.x >> 16) * (size_t)a.launch_w + (q3.x & 0xFFFFu)) * 4;
               q[0] = 0u; q[1] = 0u; q[2] = 0u; q[3] = 0u;
@@ -558,25 +560,40 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
         st_step_iters += 1; st_step_lanes += (uint32_t)__popcll(__ballot(st == ST_MARCH));
 #endif
         if (st == ST_MARCH) {
-          const float step_size = cl_max((float)sd, 0.5f);
-          ray.origin = ray.origin + ray.direction * step_size;
+          // sd is an integer in 0..127: fmaxf is cl_max here
+          ray.origin = ray.origin + ray.direction * fmaxf((float)sd, 0.5f);
           --steps_left;
-          if (exited_volume(vol, ray.origin)) {
-            ev = EV_EXIT;
-            st = ST_EVENT;
+          if (!USE_GRAD) {
+            // Has the new position a voxel?  +0 <= coordinate < dimension is ONE unsigned compare of the float's bits per axis
+            // (negative values, -0.0 and NaN all have larger patterns than any dimension).  Whatever fails it -- nearly always
+            // a ray that left the volume; else the far face, NaN or -0.0 -- is sorted out exactly in the event phase (EV_CHECK),
+            // at the event phase's price instead of eight more compares in every iteration of this loop.
+            const bool has_voxel = __float_as_uint(ray.origin.x) < __float_as_uint((float)a.X) &&
+                                   __float_as_uint(ray.origin.y) < __float_as_uint((float)a.Y) &&
+                                   __float_as_uint(ray.origin.z) < __float_as_uint((float)a.Z);
+            if (has_voxel) {
+              // the step byte says everything a table without `gradient` rules needs (classify_step's last case)
+              const unsigned q = vol.template step_marched<SMALL>(ray.origin.x, ray.origin.y, ray.origin.z);
+              sd = (int)(q & 0x7Fu);
+              if (q & 0x80u) st = ST_EVENT + EV_HIT_COLOR_PENDING;
+              else if (steps_left == 0) st = ST_EVENT + EV_NONE;
+              else if (sd >= cert_at) st = ST_CERT;  // far from every surface: can the rest of this march be proven to exit?
+            } else {
+              st = ST_EVENT + EV_CHECK;
+            }
+          } else if (exited_volume(vol, ray.origin)) {
+            st = ST_EVENT + EV_EXIT;
           } else {
             int next_sd;
             bool pending = false;
             const bool is_hit = classify_step<USE_GRAD, SMALL, true>(vol, a.tf, ray.origin, color, next_sd, &pending);
             if (is_hit) {
-              ev = pending ? EV_HIT_COLOR_PENDING : EV_HIT;
-              st = ST_EVENT;
+              st = ST_EVENT + (pending ? EV_HIT_COLOR_PENDING : EV_HIT);
             } else if (steps_left == 0) {
-              ev = EV_NONE;
-              st = ST_EVENT;
+              st = ST_EVENT + EV_NONE;
             } else {
               sd = next_sd;
-              if (cert_at != 0 && sd >= cert_at) st = ST_CERT;  // far from every surface: can the rest of this march be proven to exit?
+              if (sd >= cert_at) st = ST_CERT;
             }
           }
         }
@@ -591,10 +608,9 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
 #endif
           if (st == ST_CERT) {
             if (certify_exit(a, ray.origin, ray.direction, steps_left)) {
-              ev = EV_EXIT;       // the march WOULD end in Exit_volume; only its direction matters from here on
-              st = ST_EVENT;
+              st = ST_EVENT + EV_EXIT;  // the march WOULD end in Exit_volume; only its direction matters from here on
             } else {
-              cert_at = sd >= 64 ? 0 : max(2 * sd, cert_at);  // try again when the ray is twice as far from everything
+              cert_at = sd >= 64 ? kCertNever : max(2 * sd, cert_at);  // try again when the ray is twice as far from everything
               st = ST_MARCH;
             }
           }
@@ -607,13 +623,33 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
 
     // ---- event phase: every parked lane handles its event; the bounce is one shared block ---------
 #ifdef CLVR_BOUNCE_STATS
-    st_event_phases += 1; st_event_lanes += (uint32_t)__popcll(__ballot(st == ST_EVENT));
-    st_ev_kind[0] += (uint32_t)__popcll(__ballot(st == ST_EVENT && ev == EV_START));
-    st_ev_kind[1] += (uint32_t)__popcll(__ballot(st == ST_EVENT && ev == EV_EXIT));
-    st_ev_kind[2] += (uint32_t)__popcll(__ballot(st == ST_EVENT && (ev == EV_HIT || ev == EV_HIT_COLOR_PENDING)));
-    st_ev_kind[3] += (uint32_t)__popcll(__ballot(st == ST_EVENT && ev == EV_NONE));
+    st_event_phases += 1; st_event_lanes += (uint32_t)__popcll(__ballot(st >= ST_EVENT));
+    st_ev_kind[0] += (uint32_t)__popcll(__ballot(st == ST_EVENT + EV_START));
+    st_ev_kind[1] += (uint32_t)__popcll(__ballot(st == ST_EVENT + EV_EXIT || st == ST_EVENT + EV_CHECK));
+    st_ev_kind[2] += (uint32_t)__popcll(__ballot(st == ST_EVENT + EV_HIT || st == ST_EVENT + EV_HIT_COLOR_PENDING));
+    st_ev_kind[3] += (uint32_t)__popcll(__ballot(st == ST_EVENT + EV_NONE));
 #endif
-    if (st == ST_EVENT) {
+    if (st >= ST_EVENT) {
+      int ev = st - ST_EVENT;
+      if (ev == EV_CHECK) {
+        // the step loop's quick test found no voxel at the new position: the reference's own tests, in its order
+        // (utility_ray.cl:157-168: exited? event? out of steps?)
+        if (exited_volume(vol, ray.origin)) {
+          ev = EV_EXIT;
+        } else {
+          int next_sd;
+          bool pending = false;
+          if (classify_step<USE_GRAD, SMALL, true>(vol, a.tf, ray.origin, color, next_sd, &pending)) {
+            ev = pending ? EV_HIT_COLOR_PENDING : EV_HIT;
+          } else if (steps_left == 0) {
+            ev = EV_NONE;
+          } else {
+            sd = next_sd;
+            ev = EV_RESUMED;
+            st = ST_MARCH;
+          }
+        }
+      }
       bool start_path = (ev == EV_START);  // begin distribution ray `o` from the primary hit
       bool bounce = false, from_hit = false;
       f3 bn{0, 0, 0}, bstart{0, 0, 0};  // the bounce's normal and its origin + direction
@@ -728,11 +764,11 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
         ray = nr;
       }
 
-      if (st == ST_EVENT) {
+      if (st >= ST_EVENT) {
         // start (or continue) a march: its first SDF read is at trunc(origin) (utility_ray.cl:148-150)
         sd = (int)(vol.template step_i<SMALL>(f2i(ray.origin.x), f2i(ray.origin.y), f2i(ray.origin.z)) & 0x7Fu);
         steps_left = 70;
-        cert_at = a.cert_min_step;
+        cert_at = a.cert_min_step != 0 ? a.cert_min_step : kCertNever;
         st = ST_MARCH;
       }
     }
