@@ -443,7 +443,8 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
   int st = ST_IDLE;        // ST_IDLE / ST_MARCH / ST_CERT / ST_EVENT + event
   int sd = 0;              // SDF value for the next step of a MARCH lane
   int steps_left = 0;
-  int cert_at = kCertNever;  // the lane asks for an exit certificate once its next step is at least this long
+  // a lane asks for an exit certificate when its next step is at least this long (wave-uniform)
+  const int cert_at = a.cert_min_step != 0 ? a.cert_min_step : kCertNever;
   bool exhausted = false;  // wave-uniform: the queue has no more items
 #ifdef CLVR_BOUNCE_STATS
   uint32_t st_step_iters = 0, st_step_lanes = 0, st_event_phases = 0, st_event_lanes = 0, st_refills = 0, st_refill_lanes = 0;
@@ -610,7 +611,8 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
             if (certify_exit(a, ray.origin, ray.direction, steps_left)) {
               st = ST_EVENT + EV_EXIT;  // the march WOULD end in Exit_volume; only its direction matters from here on
             } else {
-              cert_at = sd >= 64 ? kCertNever : max(2 * sd, cert_at);  // try again when the ray is twice as far from everything
+              // it tries again at its next step that is long enough (trying less often -- only once the step has doubled, or grown by
+              // half -- left more lines to fetch than the look-ups cost: 4.03 / 3.92 / 3.91 ms)
               st = ST_MARCH;
             }
           }
@@ -768,7 +770,6 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
         // start (or continue) a march: its first SDF read is at trunc(origin) (utility_ray.cl:148-150)
         sd = (int)(vol.template step_i<SMALL>(f2i(ray.origin.x), f2i(ray.origin.y), f2i(ray.origin.z)) & 0x7Fu);
         steps_left = 70;
-        cert_at = a.cert_min_step != 0 ? a.cert_min_step : kCertNever;
         st = ST_MARCH;
       }
     }
