@@ -60,6 +60,7 @@ struct RenderArgs {
   const uint8_t *macro;
   int32_t MNX, MNY, MNZ;
   int32_t cert_min_step;   // a march asks for a certificate once its next step is at least this long; 0 = certificates off
+  int32_t cert_min_lanes;  // ... and the wave looks them up once this many lanes wait for one (launch_bounce sets it)
   int32_t NBX, NBY;
   const uint32_t *env;     // RGBA8 packed, row-major
   int32_t env_w, env_h;

@@ -313,8 +313,7 @@ __global__ __launch_bounds__(64) void k_primary(const RenderArgs a) {
 enum : int { ST_IDLE = 0, ST_MARCH = 1, ST_CERT = 2, ST_EVENT = 8 };
 enum : int { EV_START = 3,              // a freshly fetched item: start distribution ray 1
              EV_HIT_COLOR_PENDING = 4,  // a Hit whose rule colour is still to be fetched (classify_step DEFER_COLOR)
-             EV_CHECK = 5,              // the new position has no voxel: left the volume, or one of the rare in-between cases?
-             EV_RESUMED = 6 };          // (inside the event phase only) it was one of those and the march goes on
+             EV_CHECK = 5 };            // the new position has no voxel: left the volume, or one of the rare in-between cases?
 constexpr int kCertNever = 255;         // no step is this long
 
 // Image-space accumulation of one launch: a sample adds r | g<<16 | b<<32 | 1<<48 to its HIT's 64-bit
@@ -443,6 +442,7 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
   int st = ST_IDLE;        // ST_IDLE / ST_MARCH / ST_CERT / ST_EVENT + event
   int sd = 0;              // SDF value for the next step of a MARCH lane
   int steps_left = 0;
+  const int cert_min_lanes = a.cert_min_lanes;
   // a lane asks for an exit certificate when its next step is at least this long (wave-uniform)
   const int cert_at = a.cert_min_step != 0 ? a.cert_min_step : kCertNever;
   bool exhausted = false;  // wave-uniform: the queue has no more items
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
         // lookup each (certify_exit), and go back to marching or on to their Exit event; the loop, and with it the lane
         // count of the event phase, is the same as without certificates
         const int n_cert = __popcll(__ballot(st == ST_CERT));
-        if (n_cert != 0 && (n_cert >= kCertPhaseMinLanes || __popcll(__ballot(st == ST_MARCH)) < a.step_min_lanes)) {
+        if (n_cert != 0 && (n_cert >= cert_min_lanes || __popcll(__ballot(st == ST_MARCH)) < a.step_min_lanes)) {
 #ifdef CLVR_BOUNCE_STATS
           st_cert_phases += 1; st_cert_lanes += (uint32_t)n_cert;
           const int marching_before = __popcll(__ballot(st == ST_MARCH));
@@ -634,22 +634,22 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
     if (st >= ST_EVENT) {
       int ev = st - ST_EVENT;
       if (ev == EV_CHECK) {
-        // the step loop's quick test found no voxel at the new position: the reference's own tests, in its order
-        // (utility_ray.cl:157-168: exited? event? out of steps?)
-        if (exited_volume(vol, ray.origin)) {
-          ev = EV_EXIT;
-        } else {
+        // The step loop's quick test found no voxel at the new position: the reference's own tests, in its order
+        // (utility_ray.cl:157-168: exited? event? out of steps?).  Nearly always the ray has left the volume.  The rare march
+        // that goes on -- a position exactly on the far face, NaN, -0.0 -- is finished right here, step by literal step: sent
+        // back to the step loop it would come here again after every step (a NaN position has no voxel ever), and in a short
+        // launch the seventy event phases of one such ray were the tail of the whole launch (0.30 -> 0.44 ms per pass).
+        for (;;) {
+          if (exited_volume(vol, ray.origin)) { ev = EV_EXIT; break; }
           int next_sd;
           bool pending = false;
           if (classify_step<USE_GRAD, SMALL, true>(vol, a.tf, ray.origin, color, next_sd, &pending)) {
             ev = pending ? EV_HIT_COLOR_PENDING : EV_HIT;
-          } else if (steps_left == 0) {
-            ev = EV_NONE;
-          } else {
-            sd = next_sd;
-            ev = EV_RESUMED;
-            st = ST_MARCH;
+            break;
           }
+          if (steps_left == 0) { ev = EV_NONE; break; }
+          ray.origin = ray.origin + ray.direction * fmaxf((float)next_sd, 0.5f);
+          --steps_left;
         }
       }
       bool start_path = (ev == EV_START);  // begin distribution ray `o` from the primary hit
@@ -967,6 +967,10 @@ hipError_t launch_bounce(const RenderArgs &a_in, hipStream_t s) {
   const bool long_launch = !a.n_hits_on_device && waves_needed >= 6u * (uint64_t)blocks * wpb;
   if (a.step_min_lanes <= 0) a.step_min_lanes = long_launch ? 16 : 1;
   if (a.refill_min_lanes <= 0) a.refill_min_lanes = long_launch ? 16 : 64;
+  // certificates: a long launch looks them up once 16 lanes of a wave wait for one (8: 4.32, 16: 4.25, 4: 4.42 ms); a short launch
+  // is bound by its longest chain of dependent fetches, where the look-up is one more of them: 0.263 ms per pass without, 0.277 with
+  a.cert_min_lanes = kCertPhaseMinLanes;
+  if (!long_launch) a.cert_min_step = 0;
   if ((uint64_t)(((a.n_hits + 63u) >> 6) + 8u * (1u << a.unit_block_log2)) * (uint64_t)a.n_seeds >= (1ull << 24)) return hipErrorInvalidValue;  // udivmod24
   const bool g = a.tf.uses_gradient != 0;
   // fewer than 2^23 bricks (up to ~1600^3): every step byte has a 32-bit offset -> the march's 32-bit addressing, with
