@@ -93,6 +93,7 @@ struct RenderArgs {
   // scheduling knobs of k_bounce (defaults in clwh_runtime.hip; CLWH_TUNE_* override for experiments)
   int32_t step_min_lanes;    // keep stepping while at least this many lanes march
   int32_t refill_min_lanes;  // idle lanes fetch new items once this many are idle (64: only an empty wave refills)
+  int32_t force_long_launch; // tests: schedule every launch like a long one (thresholds 16 / 16, exit certificates)
   uint32_t bounce_max_blocks;  // persistent grid size (256-thread blocks)
   int32_t unit_group;          // chunks per queue group (see k_bounce refill)
   int32_t unit_block_log2;     // 2^n consecutive chunks go to the same queue
@@ -209,6 +210,7 @@ struct clwh_ctx {
   // steps and events in separate wave-wide phases beats mid-flight refills (12.5 vs 7.6 Gsamples/s)
   int32_t tune_step_min_lanes = 0;    // 0: chosen per launch (launch_bounce)
   int32_t tune_refill_min_lanes = 0;  // 0: chosen per launch (launch_bounce)
+  int32_t tune_force_long_launch = 0; // CLWH_TUNE_LONG_LAUNCH=1: every launch is scheduled like a long one (the parity tests use it)
   int32_t tune_literal_gradient = 0;
   int32_t tune_unit_block_log2 = 4;
   int32_t tune_unit_group = 1, tune_unit_affinity = 0, tune_unit_queues = 8;

@@ -171,6 +171,7 @@ int clwh_ctx_create_on_stream(int device, void *hip_stream, clwh_ctx **out) {
   if (const char *e = std::getenv("CLWH_TUNE_GROUP")) c->tune_unit_group = std::max(1, std::atoi(e));
   if (const char *e = std::getenv("CLWH_TUNE_CHUNK_BLOCK_LOG2")) c->tune_unit_block_log2 = std::max(0, std::min(8, std::atoi(e)));
   if (const char *e = std::getenv("CLWH_TUNE_BLOCKS")) c->tune_bounce_max_blocks = (uint32_t)std::max(1, std::atoi(e));
+  if (const char *e = std::getenv("CLWH_TUNE_LONG_LAUNCH")) c->tune_force_long_launch = std::atoi(e) != 0;
   if (const char *e = std::getenv("CLWH_TUNE_CERT")) c->tune_cert_min_step = std::max(0, std::min(127, std::atoi(e)));
   *out = c;
   return CLWH_OK;
@@ -685,6 +686,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   a.tf.literal_gradient_taps = ctx->tune_literal_gradient;
   a.step_min_lanes = ctx->tune_step_min_lanes;
   a.refill_min_lanes = ctx->tune_refill_min_lanes;
+  a.force_long_launch = ctx->tune_force_long_launch;
   a.bounce_max_blocks = ctx->tune_bounce_max_blocks;
   a.unit_group = ctx->tune_unit_group;
   a.unit_block_log2 = ctx->tune_unit_block_log2;

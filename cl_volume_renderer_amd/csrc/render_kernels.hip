@@ -964,7 +964,7 @@ hipError_t launch_bounce(const RenderArgs &a_in, hipStream_t s) {
   // Measured crossover on the headline scene: between 4 and 8 passes per launch = about 6 units per wave
   // (profiles/r01_tune_refill_step_thresholds.txt).
   // (with the hit count still on the device n_hits is the pixel count, an upper bound: such launches are single-pass)
-  const bool long_launch = !a.n_hits_on_device && waves_needed >= 6u * (uint64_t)blocks * wpb;
+  const bool long_launch = a.force_long_launch || (!a.n_hits_on_device && waves_needed >= 6u * (uint64_t)blocks * wpb);
   if (a.step_min_lanes <= 0) a.step_min_lanes = long_launch ? 16 : 1;
   if (a.refill_min_lanes <= 0) a.refill_min_lanes = long_launch ? 16 : 64;
   // certificates: a long launch looks them up once 16 lanes of a wave wait for one (8: 4.32, 16: 4.25, 4: 4.42 ms); a short launch

@@ -77,3 +77,19 @@ def gpu_ctx():
     ctx = ffi.Context(0)
     yield ctx
     ctx.destroy()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_long():
+    """A second context that schedules EVERY k_bounce launch like a long one (refill / step thresholds 16 / 16, exit
+    certificates on: csrc/render_kernels.hip launch_bounce), so that small scenes exercise the code the 64-pass headline
+    launch runs.  The knob is read when the context is created."""
+    from cl_volume_renderer_amd import ffi
+
+    os.environ["CLWH_TUNE_LONG_LAUNCH"] = "1"
+    try:
+        ctx = ffi.Context(0)
+    finally:
+        del os.environ["CLWH_TUNE_LONG_LAUNCH"]
+    yield ctx
+    ctx.destroy()

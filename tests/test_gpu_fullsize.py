@@ -84,6 +84,12 @@ def test_job_level_properties_without_the_oracle(full):
     assert set(np.unique(fused[:, 3])) == {0.0, 64.0}        # every hit pixel got exactly one sample per pass
     assert not fused[~hit].any()
     assert fused[hit, :3].max() <= 64 * 255
+    # the 16-pass launches are LONG launches (lanes refill early, exit certificates on); one pass per launch is a short one
+    # (every wave marches its samples to completion, no certificates): the same sums, bit for bit
+    ctx.buffer_reset(g.accum[0])
+    for s in seeds:
+        g.render(pos, d, s, mode=ffi.ACCUM_IMAGE_SPACE, debug=False, write_frame=False)
+    assert np.array_equal(g.accum[0].pull(np.float32).reshape(-1, 4), fused)
     ctx.buffer_reset(g.accum[0])
     for s in seeds[:8]:
         g.render(pos, d, s, mode=ffi.ACCUM_IMAGE_SPACE, debug=False, write_frame=False)
@@ -190,9 +196,14 @@ def test_config3_gradient_tf_at_full_size(gpu_ctx, orc):
     gpu_ctx.buffer_reset(g.accum[0])
     for k in range(0, 256, 64):
         g.render(pos, d, None, mode=ffi.ACCUM_IMAGE_SPACE, seeds=seeds[k:k + 64], debug=False, write_frame=False)
-    acc = g.accum[0].pull(np.float32).reshape(-1, 4)
+    acc = g.accum[0].pull(np.float32).reshape(-1, 4).copy()
     assert set(np.unique(acc[:, 3])) == {0.0, 256.0} and int((acc[:, 3] > 0).sum()) == n_hit
     assert acc[:, :3].max() <= 256 * 255
+    # the same 256 passes one per launch (short launches: no exit certificates, every wave marches to completion)
+    gpu_ctx.buffer_reset(g.accum[0])
+    for s in seeds:
+        g.render(pos, d, s, mode=ffi.ACCUM_IMAGE_SPACE, debug=False, write_frame=False)
+    assert np.array_equal(g.accum[0].pull(np.float32).reshape(-1, 4), acc)
     # 256 spp, reference-exact voxel cache, one pass per launch: the cap is reached and never exceeded
     gpu_ctx.buffer_reset(g.cache)
     for s in seeds:
