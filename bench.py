@@ -608,7 +608,8 @@ def main():
                               "what": "bytes ACTUALLY moved at the L2's memory side per launch (profiled run) / this run's launch "
                                       "duration: every missing 1-byte gather moves a 128-byte line"} if tb else None),
             "traffic_note": (tb or {}).get("note", "GB per launch from rocprofv3 --pmc (profiles/r02_traffic.json); null: this launch shape was not profiled"),
-            "limiter": "dependent 1-byte gathers: L2-miss request rate and VALU issue, not HBM bytes (DESIGN.md 4)",
+            "limiter": "dependent 1-byte gathers: the rate of L2-missing 128-byte lines (about 41 G/s of the 48-54 G/s a plain random-load "
+                       "probe reaches) together with VALU issue (84 % busy), not algorithmic HBM bytes (DESIGN.md 4)",
             "bytes_per_sample": round(bytes_bounce(c) / float(own_px), 3),
             "samples_per_launch": int(own_px * passes_per_launch),
             "algorithmic_gb_per_launch": round(bounce_bytes / 1e9, 4),
