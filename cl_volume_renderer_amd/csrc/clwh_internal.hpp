@@ -58,7 +58,7 @@ struct RenderArgs {
   // exit certificates (render_kernels.hip, certify_exit): eight bytes per macro cell of 16^3 voxels; byte o: a bound on the steps of a
   // march from this cell in direction octant o until it leaves the volume, 255 = the box it crosses is not free
   const uint8_t *macro;
-  int32_t MNX, MNY, MNZ;
+  int32_t MNX, MNY, MNZ, macro_shift;  // cells per axis, log2 of the cell's edge in voxels
   int32_t cert_min_step;   // a march asks for a certificate once its next step is at least this long; 0 = certificates off
   int32_t cert_min_lanes;  // ... and the wave looks them up once this many lanes wait for one (launch_bounce sets it)
   int32_t NBX, NBY;
@@ -141,7 +141,15 @@ struct JitTf {
 
 // host-side launchers implemented in the .hip files
 hipError_t launch_repack(const RepackArgs &a, hipStream_t s);
-hipError_t launch_macro_table(const uint32_t *brick_min, int NBX, int NBY, int NBZ, uint8_t *macro, int MNX, int MNY, int MNZ, int X, int Y, int Z, hipStream_t s);
+// log2 of the macro cell's edge: 16 voxels up to 512^3, then growing with the volume so that the table (8 B per cell) stays at a
+// few hundred KB, resident in every L2 -- at 2048^3 cells of 16^3 would make it 16 MiB and every look-up a miss of its own
+inline int macro_cell_shift(int X, int Y, int Z, int forced) {
+  if (forced >= 4 && forced <= 8) return forced;  // CLWH_TUNE_MACRO_SHIFT (tests)
+  int shift = 4;
+  while (shift < 8 && ((int64_t)((X >> shift) + 1) * ((Y >> shift) + 1) * ((Z >> shift) + 1)) > 40000) ++shift;
+  return shift;
+}
+hipError_t launch_macro_table(const uint32_t *brick_min, int NBX, int NBY, int NBZ, uint8_t *macro, int X, int Y, int Z, int shift, hipStream_t s);
 hipError_t launch_primary(const RenderArgs &a, hipStream_t s);
 hipError_t launch_bounce(const RenderArgs &a, hipStream_t s);
 hipError_t launch_env_fixup(const RenderArgs &a, hipStream_t s);
@@ -210,11 +218,13 @@ struct clwh_ctx {
   // steps and events in separate wave-wide phases beats mid-flight refills (12.5 vs 7.6 Gsamples/s)
   int32_t tune_step_min_lanes = 0;    // 0: chosen per launch (launch_bounce)
   int32_t tune_refill_min_lanes = 0;  // 0: chosen per launch (launch_bounce)
+  int32_t tune_macro_shift = 0;       // CLWH_TUNE_MACRO_SHIFT: 4..8 forces the macro cell's edge to 2^n voxels (0: by volume size)
   int32_t tune_force_long_launch = 0; // CLWH_TUNE_LONG_LAUNCH=1: every launch is scheduled like a long one (the parity tests use it)
   int32_t tune_literal_gradient = 0;
   int32_t tune_unit_block_log2 = 4;
   int32_t tune_unit_group = 1, tune_unit_affinity = 0, tune_unit_queues = 8;
-  int32_t tune_cert_min_step = 16;  // CLWH_TUNE_CERT: 0 = exit certificates off
+  int32_t tune_cert_min_step = -1;  // CLWH_TUNE_CERT: 0 = exit certificates off; -1 = by volume size (16 at 512^3, 32 at 1024^3, 48 at 2048^3:
+                                    // the best of the sweeps in profiles/r02_sweep_k_bounce_lds_state.txt)
   uint32_t tune_bounce_max_blocks = 2048;
   bool primary_valid = false;
   uint32_t primary_n_hits = 0;

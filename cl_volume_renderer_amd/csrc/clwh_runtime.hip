@@ -171,6 +171,7 @@ int clwh_ctx_create_on_stream(int device, void *hip_stream, clwh_ctx **out) {
   if (const char *e = std::getenv("CLWH_TUNE_GROUP")) c->tune_unit_group = std::max(1, std::atoi(e));
   if (const char *e = std::getenv("CLWH_TUNE_CHUNK_BLOCK_LOG2")) c->tune_unit_block_log2 = std::max(0, std::min(8, std::atoi(e)));
   if (const char *e = std::getenv("CLWH_TUNE_BLOCKS")) c->tune_bounce_max_blocks = (uint32_t)std::max(1, std::atoi(e));
+  if (const char *e = std::getenv("CLWH_TUNE_MACRO_SHIFT")) c->tune_macro_shift = std::atoi(e);
   if (const char *e = std::getenv("CLWH_TUNE_LONG_LAUNCH")) c->tune_force_long_launch = std::atoi(e) != 0;
   if (const char *e = std::getenv("CLWH_TUNE_CERT")) c->tune_cert_min_step = std::max(0, std::min(127, std::atoi(e)));
   *out = c;
@@ -527,7 +528,8 @@ static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *
   const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 7) / 8;
   const size_t records = (size_t)NBX * NBY * NBZ * 512u;
   const size_t n_bricks = (size_t)NBX * NBY * NBZ;
-  const int MNX = (X + 15) / 16, MNY = (Y + 15) / 16, MNZ = (Z + 15) / 16;  // macro cells of the exit certificates
+  const int mshift = macro_cell_shift(X, Y, Z, ctx->tune_macro_shift), mcell = 1 << mshift;  // macro cells of the exit certificates
+  const int MNX = (X + mcell - 1) >> mshift, MNY = (Y + mcell - 1) >> mshift, MNZ = (Z + mcell - 1) >> mshift;
   // hit records, the per-step bytes, the per-brick minima (u32, 16-byte aligned), the macro-cell table
   const size_t off_brick_min = (records * (sizeof(uint2) + 1u) + 15u) & ~(size_t)15u;
   const size_t off_macro = (off_brick_min + n_bricks * sizeof(uint32_t) + 15u) & ~(size_t)15u;
@@ -564,7 +566,7 @@ static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *
     int trc = t.begin(ctx, CLWH_TIMER_REPACK);
     if (trc != CLWH_OK) return trc;
     HIP_TRY(launch_repack(r, ctx->stream));
-    HIP_TRY(launch_macro_table(r.brick_min, NBX, NBY, NBZ, ctx->packed + off_macro, MNX, MNY, MNZ, X, Y, Z, ctx->stream));
+    HIP_TRY(launch_macro_table(r.brick_min, NBX, NBY, NBZ, ctx->packed + off_macro, X, Y, Z, mshift, ctx->stream));
     trc = t.end();
     if (trc != CLWH_OK) return trc;
   }
@@ -706,13 +708,16 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     const size_t records = (size_t)a.NBX * a.NBY * ((a.Z + 7) / 8) * 512u, n_bricks = records / 512u;
     const size_t off_brick_min = (records * (sizeof(uint2) + 1u) + 15u) & ~(size_t)15u;
     a.macro = ctx->packed + ((off_brick_min + n_bricks * sizeof(uint32_t) + 15u) & ~(size_t)15u);
-    a.MNX = (a.X + 15) / 16; a.MNY = (a.Y + 15) / 16; a.MNZ = (a.Z + 15) / 16;
+    a.macro_shift = macro_cell_shift(a.X, a.Y, a.Z, ctx->tune_macro_shift);
+    const int mcell = 1 << a.macro_shift;
+    a.MNX = (a.X + mcell - 1) >> a.macro_shift; a.MNY = (a.Y + mcell - 1) >> a.macro_shift; a.MNZ = (a.Z + mcell - 1) >> a.macro_shift;
     // An exit certificate proves "this march leaves the volume without a Hit"; a position with a coordinate == dimension or NaN
     // reads the border texel (value 0), so tables under which value 0 can be an event keep marching literally.
     bool zero_may_hit = a.tf.border_class != 0;
     for (int q = 0; q < a.tf.n && a.tf.uses_gradient && !a.tf.opaque; ++q)
       if (a.tf.rules[q].v_lo <= 0 && 0 <= a.tf.rules[q].v_hi) zero_may_hit = true;
-    a.cert_min_step = zero_may_hit ? 0 : ctx->tune_cert_min_step;
+    const int cert_auto = std::min(16 << (a.macro_shift - 4), 48);
+    a.cert_min_step = zero_may_hit ? 0 : (ctx->tune_cert_min_step >= 0 ? ctx->tune_cert_min_step : cert_auto);
   }
 
   // ---- primary hits of this camera: rebuilt only when something they depend on changed

@@ -144,7 +144,8 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
   }
 }
 
-// Exit-certificate table (certify_exit below).  One entry per macro cell of 16^3 voxels and direction octant o
+// Exit-certificate table (certify_exit below).  One entry per macro cell (16^3 voxels up to 512^3, growing with the volume:
+// macro_cell_shift in clwh_internal.hpp) and direction octant o
 // (o = [d.x < 0] | [d.y < 0] << 1 | [d.z < 0] << 2): a march that starts anywhere in the cell with a direction of that
 // octant stays in the box between the cell and the volume corner the octant heads for.  The entry is an upper bound of
 // the number of steps such a march takes until it leaves the volume, or 255 if the box is not free.
@@ -157,14 +158,15 @@ constexpr uint32_t kCertMinStep = 2u;
 #endif
 constexpr int kCertPhaseMinLanes = CLVR_CERT_PHASE_MIN_LANES;  // certificates are looked up once this many lanes of a wave wait for one
 __global__ __launch_bounds__(256) void k_macro_table(const uint32_t *__restrict__ brick_min, int NBX, int NBY, int NBZ,
-                                                     uint2 *__restrict__ macro, int MNX, int MNY, int MNZ) {
+                                                     uint2 *__restrict__ macro, int MNX, int MNY, int MNZ, int shift) {
   const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (c >= MNX * MNY * MNZ) return;
   const int cx = c % MNX, cy = (c / MNX) % MNY, cz = c / (MNX * MNY);
   uint32_t m = 255u;
-  for (int bz = max(cz * 2 - 1, 0); bz <= min(cz * 2 + 2, NBZ - 1); ++bz)
-    for (int by = max(cy * 2 - 1, 0); by <= min(cy * 2 + 2, NBY - 1); ++by)
-      for (int bx = max(cx * 2 - 1, 0); bx <= min(cx * 2 + 2, NBX - 1); ++bx)
+  const int bpc = 1 << (shift - 3);  // bricks per cell and axis
+  for (int bz = max(cz * bpc - 1, 0); bz <= min(cz * bpc + bpc, NBZ - 1); ++bz)
+    for (int by = max(cy * bpc - 1, 0); by <= min(cy * bpc + bpc, NBY - 1); ++by)
+      for (int bx = max(cx * bpc - 1, 0); bx <= min(cx * bpc + bpc, NBX - 1); ++bx)
         m = min(m, brick_min[((size_t)bz * (size_t)NBY + (size_t)by) * (size_t)NBX + (size_t)bx]);
   if (m < kCertMinStep) m = 0u;
   m *= 0x01010101u;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(64) void k_macro_octants(uint2 *__restrict__ macro,
 // Step 3: box minimum -> step bound.  The longest path inside the box is its diagonal (a unit direction with
 // t = e.x / |d.x| = e.y / |d.y| = e.z / |d.z| has t = |e|), every step there is max(sdf, 0.5) >= the box minimum long, so
 // diagonal / minimum steps leave the volume; + 5 covers the roundings of this bound and of the march.
-__global__ __launch_bounds__(256) void k_macro_bounds(uint2 *__restrict__ macro, int MNX, int MNY, int MNZ, int X, int Y, int Z) {
+__global__ __launch_bounds__(256) void k_macro_bounds(uint2 *__restrict__ macro, int MNX, int MNY, int MNZ, int X, int Y, int Z, int shift) {
   const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (c >= MNX * MNY * MNZ) return;
   const int cx = c % MNX, cy = (c / MNX) % MNY, cz = c / (MNX * MNY);
@@ -221,9 +223,10 @@ __global__ __launch_bounds__(256) void k_macro_bounds(uint2 *__restrict__ macro,
   uint2 r = make_uint2(0u, 0u);
   for (int o = 0; o < 8; ++o) {
     const uint32_t m = ((o < 4 ? v.x : v.y) >> ((o & 3) * 8)) & 0xFFu;
-    const float ex = (o & 1) ? (float)(cx * 16 + 16) : (float)(X - cx * 16);
-    const float ey = (o & 2) ? (float)(cy * 16 + 16) : (float)(Y - cy * 16);
-    const float ez = (o & 4) ? (float)(cz * 16 + 16) : (float)(Z - cz * 16);
+    const int M = 1 << shift;
+    const float ex = (o & 1) ? (float)(cx * M + M) : (float)(X - cx * M);
+    const float ey = (o & 2) ? (float)(cy * M + M) : (float)(Y - cy * M);
+    const float ez = (o & 4) ? (float)(cz * M + M) : (float)(Z - cz * M);
     uint32_t steps = 255u;
     if (m != 0u) steps = (uint32_t)fminf(sqrtf(ex * ex + ey * ey + ez * ez) / (float)m + 5.0f, 255.0f);
     if (o < 4) r.x |= steps << (o * 8); else r.y |= steps << ((o - 4) * 8);
@@ -376,8 +379,8 @@ constexpr int kFixupDwords = 32;  // one record = 128 B: header[4] bv_before[3] 
 // one certificate in millions was wrong.
 __device__ __forceinline__ bool certify_exit(const RenderArgs &a, f3 p, f3 d, int budget) {
   // the position has a voxel or sits on the far face: 0 <= p <= dim (or -0.0)
-  const unsigned cx = min((unsigned)(int)p.x >> 4, (unsigned)a.MNX - 1u), cy = min((unsigned)(int)p.y >> 4, (unsigned)a.MNY - 1u),
-                 cz = min((unsigned)(int)p.z >> 4, (unsigned)a.MNZ - 1u);
+  const unsigned cx = min((unsigned)(int)p.x >> a.macro_shift, (unsigned)a.MNX - 1u), cy = min((unsigned)(int)p.y >> a.macro_shift, (unsigned)a.MNY - 1u),
+                 cz = min((unsigned)(int)p.z >> a.macro_shift, (unsigned)a.MNZ - 1u);
   const unsigned octant = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
   const int bound = a.macro[((((size_t)cz * (size_t)a.MNY + (size_t)cy) * (size_t)a.MNX + (size_t)cx) << 3) | octant];
   const float dsum = d.x + d.y + d.z;  // NaN direction: the position turns NaN and never leaves
@@ -930,14 +933,16 @@ hipError_t launch_repack(const RepackArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_macro_table(const uint32_t *brick_min, int NBX, int NBY, int NBZ, uint8_t *macro8, int MNX, int MNY, int MNZ, int X, int Y, int Z, hipStream_t s) {
+hipError_t launch_macro_table(const uint32_t *brick_min, int NBX, int NBY, int NBZ, uint8_t *macro8, int X, int Y, int Z, int shift, hipStream_t s) {
+  const int M = 1 << shift;
+  const int MNX = (X + M - 1) >> shift, MNY = (Y + M - 1) >> shift, MNZ = (Z + M - 1) >> shift;
   uint2 *macro = reinterpret_cast<uint2 *>(macro8);
   const unsigned n = (unsigned)(MNX * MNY * MNZ);
-  hipLaunchKernelGGL(k_macro_table, dim3((n + 255u) / 256u), dim3(256), 0, s, brick_min, NBX, NBY, NBZ, macro, MNX, MNY, MNZ);
+  hipLaunchKernelGGL(k_macro_table, dim3((n + 255u) / 256u), dim3(256), 0, s, brick_min, NBX, NBY, NBZ, macro, MNX, MNY, MNZ, shift);
   const int lines[3] = {MNY * MNZ, MNZ * MNX, MNX * MNY};
   for (int axis = 0; axis < 3; ++axis)
     hipLaunchKernelGGL(k_macro_octants, dim3(((unsigned)lines[axis] + 63u) / 64u), dim3(64), 0, s, macro, MNX, MNY, MNZ, axis);
-  hipLaunchKernelGGL(k_macro_bounds, dim3((n + 255u) / 256u), dim3(256), 0, s, macro, MNX, MNY, MNZ, X, Y, Z);
+  hipLaunchKernelGGL(k_macro_bounds, dim3((n + 255u) / 256u), dim3(256), 0, s, macro, MNX, MNY, MNZ, X, Y, Z, shift);
   return hipGetLastError();
 }
 

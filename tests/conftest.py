@@ -93,3 +93,19 @@ def gpu_ctx_long():
         del os.environ["CLWH_TUNE_LONG_LAUNCH"]
     yield ctx
     ctx.destroy()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_long_big_cells():
+    """gpu_ctx_long with the exit certificates' macro cells forced to 64^3 voxels -- what a 2048^3 volume gets by itself"""
+    from cl_volume_renderer_amd import ffi
+
+    os.environ["CLWH_TUNE_LONG_LAUNCH"] = "1"
+    os.environ["CLWH_TUNE_MACRO_SHIFT"] = "6"
+    try:
+        ctx = ffi.Context(0)
+    finally:
+        del os.environ["CLWH_TUNE_LONG_LAUNCH"]
+        del os.environ["CLWH_TUNE_MACRO_SHIFT"]
+    yield ctx
+    ctx.destroy()

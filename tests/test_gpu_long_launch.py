@@ -44,6 +44,18 @@ def test_ball_in_empty_space_certificates_granted(gpu_ctx_long, orc, mode):
     assert hits > 2000
 
 
+def test_macro_cells_of_64_voxels(gpu_ctx_long_big_cells, orc):
+    """large volumes get larger cells (clwh_internal.hpp macro_cell_shift); forced here on a 200 x 170 x 150 volume"""
+    vol = np.full((150, 170, 200), -800, np.int16)
+    z, y, x = np.mgrid[0:150, 0:170, 0:200].astype(np.float32)
+    r = np.sqrt((x - 150) ** 2 + (y - 120) ** 2 + (z - 100) ** 2)
+    vol[r < 28] = 900
+    env = scene.env_map(256, 128)
+    pos, d = look_at_centre(vol, [-40, 230, -50])
+    hits = _parity(orc, gpu_ctx_long_big_cells, vol, env, scene.tf_default_source(), (256, 160), pos, d, scene.glibc_rand(4))
+    assert hits > 500
+
+
 def test_non_cubic_volume_with_ragged_macro_cells(gpu_ctx_long, orc):
     """dimensions that are no multiples of the brick (8) or the macro cell (16): 150 x 70 x 41"""
     rng = np.random.default_rng(9)
