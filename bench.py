@@ -504,6 +504,12 @@ def main():
     for _ in range(regions):
         region_s.append(timed_region(job, K))
         job += K
+    # the estimate came from single jobs, which do not overlap: add regions until MIN_TIMED_SECONDS really have been timed
+    # (the decision is taken on a value every rank agrees on)
+    while not args.single_region and len(region_s) < MAX_REGIONS and max_over_ranks([sum(region_s)])[0] < MIN_TIMED_SECONDS:
+        region_s.append(timed_region(job, K))
+        job += K
+    regions = len(region_s)
     # kernel durations for the roofline: HIP events around every launch, in a separate region in which the frame jobs run
     # strictly one after the other on one stream -- with two frames in flight a launch's events would also span the time it
     # shares the GPU with the other frame's kernels
