@@ -127,3 +127,31 @@ def test_fused_long_launch_equals_the_passes_one_by_one(gpu_ctx, gpu_ctx_long, o
         g.release()
     assert acc[0][:, 3].max() == 12.0
     assert np.array_equal(acc[0], acc[1])
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_random_scenes_under_long_launch_scheduling(gpu_ctx_long, gpu_ctx_long_big_cells, orc, case):
+    """random blobs in a mostly empty, non-cubic volume, random rectangle tables (with and without `gradient` clauses, some
+    containing the border value 0), random cameras inside and outside: certificates granted, refused and switched off"""
+    rng = np.random.default_rng(4000 + case)
+    X, Y, Z = (int(rng.integers(40, 150)) for _ in range(3))
+    vol = np.full((Z, Y, X), -900, np.int16)
+    z, y, x = np.mgrid[0:Z, 0:Y, 0:X].astype(np.float32)
+    for _ in range(int(rng.integers(1, 5))):
+        c = rng.random(3) * np.array([X, Y, Z])
+        r = float(rng.integers(4, max(6, min(X, Y, Z) // 3)))
+        d2 = (x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2
+        vol[d2 < r * r] = np.int16(rng.integers(200, 1300))
+    vol += rng.integers(-40, 40, size=vol.shape, dtype=np.int16)
+    rects = []
+    for _ in range(int(rng.integers(1, 3))):
+        lo = float(rng.integers(100, 900)) if rng.random() < 0.8 else float(rng.integers(-1000, -100))
+        hi = lo + float(rng.integers(100, 1200))
+        glo, ghi = (float(rng.integers(0, 300)), float(rng.integers(800, 3999))) if rng.random() < 0.4 else (0.0, 4000.0)
+        rects.append((lo, hi, glo, ghi, tuple(float(v) for v in rng.random(4))))
+    tf = scene.tf_rect_source(rects)
+    env = scene.env_map(128, 64, seed=case)
+    eye = [float(rng.integers(-60, X + 60)), float(rng.integers(-60, Y + 60)), float(rng.integers(-60, Z + 60))]
+    pos, d = look_at_centre(vol, eye)
+    ctx = gpu_ctx_long_big_cells if case % 4 == 3 else gpu_ctx_long
+    _parity(orc, ctx, vol, env, tf, (160, 96), pos, d, scene.glibc_rand(3), mode="voxel" if case % 2 else "image")
