@@ -7,7 +7,7 @@ app/renderer.cpp:131-158), synthetic seeded inputs.
 
 A STEP is one whole frame job of the config: the first frame after a camera move -- primary hits of the
 camera (k_primary), `spp` render passes with fresh glibc-rand() seeds in launches of 64 passes each
-(k_bounce + k_env_fixup + k_commit), [N > 1: ONE RCCL all-gather of the float4 accumulation tiles], resolve
+(k_bounce + k_env_fixup + k_commit), resolve [N > 1: of the rank's own tiles, then ONE RCCL all-gather of RGBA8 tiles]
 to the RGBA8 frame.  `--steps K` times exactly K such jobs between barrier + synchronize brackets; because K
 jobs of the headline config take only K x 5.5 ms, the K-step region is repeated until at least
 MIN_TIMED_SECONDS have been measured and the MEDIAN region is reported (every region's time is the max over
@@ -450,10 +450,12 @@ def main():
             lkernel = lctx.kernel("ray_marching.cl", "render", tf_source)
         with torch.cuda.stream(stream):
             acc = torch.zeros(n_acc * 4, dtype=torch.float32, device=dev)
-            acc_all = torch.zeros(n_acc * 4 * world, dtype=torch.float32, device=dev)
+            # N > 1: the rank's tiles resolved to RGBA8 (4 B per pixel) are what the ranks exchange
+            tl = torch.zeros(n_acc, dtype=torch.int32, device=dev)
+            tl_all = torch.zeros(n_acc * world, dtype=torch.int32, device=dev)
         lanes.append(dict(stream=stream, ctx=lctx, vol=lvol, sdf=lsdf, env=lenv, frame=lframe, kernel=lkernel, accum=acc,
-                          accum_all=acc_all, m_accum=lctx.wrap(acc.data_ptr(), acc.numel() * 4),
-                          m_accum_all=lctx.wrap(acc_all.data_ptr(), acc_all.numel() * 4)))
+                          m_accum=lctx.wrap(acc.data_ptr(), acc.numel() * 4), tiles=tl, tiles_all=tl_all,
+                          m_tiles=lctx.wrap(tl.data_ptr(), tl.numel() * 4), m_tiles_all=lctx.wrap(tl_all.data_ptr(), tl_all.numel() * 4)))
     torch.cuda.synchronize()
 
     # seeds: the glibc rand() stream the never-seeded reference draws from, one per pass, continuing over the jobs
@@ -475,8 +477,13 @@ def main():
                 ln["kernel"].render(frame=None, volume=ln["vol"], sdf=ln["sdf"], env=ln["env"], accum=ln["m_accum"], cam_pos=pos,
                                     cam_dir=cdir, seed=0, seeds=sd[i:i + S], width=W, height=H, mode=ffi.ACCUM_IMAGE_SPACE,
                                     tile_rank=rank, tile_world=world, write_frame=False)
-            tiles.gather_accum(ln["accum"], ln["accum_all"], world)  # N>1: ONE RCCL all-gather of the float4 tiles over xGMI
-            ln["ctx"].accum_resolve(ln["m_accum_all"], world, W, H, ln["frame"], ln["env"], pos, cdir)
+            if world == 1:
+                ln["ctx"].accum_resolve(ln["m_accum"], 1, W, H, ln["frame"], ln["env"], pos, cdir)
+            else:
+                # resolve this rank's tiles, then ONE RCCL all-gather of RGBA8 tiles over xGMI (4 B per pixel, not 16), then place them
+                ln["ctx"].accum_resolve_tiles(ln["m_accum"], rank, world, W, H, ln["m_tiles"], ln["env"], pos, cdir)
+                tiles.gather_accum(ln["tiles"], ln["tiles_all"], world)
+                ln["ctx"].frame_from_tiles(ln["m_tiles_all"], world, W, H, ln["frame"])
             if pull:
                 return ln["frame"].pull()
         return None
@@ -548,7 +555,7 @@ def main():
                         "(1 spp per render pass), SDF empty-space skip, %s TF" % (
                             args.config - 1, N, args.env[0], args.env[1], W, H, SPP, args.tf),
             "step": "one frame job: k_primary (camera changed) + %d passes in %d launch(es) of <= %d + %s resolve to RGBA8" % (
-                SPP, (SPP + S - 1) // S, S, "RCCL all-gather + " if world > 1 else ""),
+                SPP, (SPP + S - 1) // S, S, "RCCL all-gather of the resolved RGBA8 tiles + " if world > 1 else ""),
             "accumulation": "image-space float4 per pixel, 8x8 tiles interleaved over ranks",
             "passes_per_launch": S,
             "frames_in_flight": n_lanes,

@@ -157,6 +157,8 @@ hipError_t launch_commit(const RenderArgs &a, hipStream_t s);
 hipError_t launch_resolve(const RenderArgs &a, hipStream_t s);
 hipError_t launch_ao(const RenderArgs &a, hipStream_t s);
 hipError_t launch_accum_resolve(const RenderArgs &a, const float4 *accum_all, hipStream_t s);
+hipError_t launch_accum_resolve_tiles(const RenderArgs &a, const float4 *accum, uint32_t *tiles_out, hipStream_t s);
+hipError_t launch_frame_from_tiles(const RenderArgs &a, const uint32_t *tiles_all, hipStream_t s);
 // ---- fused SDF build: one breadth-first layer over the active 8x8x8 tiles (sdf_kernels.hip)
 struct SdfFrontArgs {
   int8_t *sdf;

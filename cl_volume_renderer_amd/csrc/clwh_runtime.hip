@@ -878,6 +878,49 @@ int clwh_accum_resolve(clwh_ctx *ctx, clwh_mem *accum_all, int32_t tile_world, u
   return CLWH_OK;
 }
 
+int clwh_accum_resolve_tiles(clwh_ctx *ctx, clwh_mem *accum, int32_t tile_rank, int32_t tile_world, uint32_t width, uint32_t height,
+                             clwh_mem *tiles_rgba8, clwh_mem *env, const float cam_pos[3], const float cam_dir[3]) {
+  if (!ctx || !accum || !tiles_rgba8 || !env || !cam_pos || !cam_dir || tile_world < 1 || tile_rank < 0 || tile_rank >= tile_world)
+    return CLWH_ERR_INVALID_VALUE;
+  if (!is_image(env, 2, 4, CLWH_ELEM_U8)) return CLWH_ERR_BAD_ARGS;
+  if (width == 0 || height == 0 || (width % 8) || (height % 8)) return CLWH_ERR_BAD_NDRANGE;
+  const int64_t n = clwh_accum_len(width, height, tile_world);
+  if ((int64_t)accum->bytes < n * 16 || (int64_t)tiles_rgba8->bytes < n * 4) return CLWH_ERR_SIZE_MISMATCH;
+  RenderArgs a;
+  std::memset(&a, 0, sizeof a);
+  describe_frame(a, (int32_t)width, (int32_t)height, (int32_t)width, (int32_t)height, tile_rank, tile_world, cam_pos, cam_dir);
+  a.env = (const uint32_t *)env->dptr;
+  a.env_w = (int32_t)env->dims[0];
+  a.env_h = (int32_t)env->dims[1];
+  HIP_TRY(hipSetDevice(ctx->device));
+  {
+    TimedLaunch t;
+    int trc = t.begin(ctx, CLWH_TIMER_RESOLVE);
+    if (trc != CLWH_OK) return trc;
+    HIP_TRY(launch_accum_resolve_tiles(a, (const float4 *)accum->dptr, (uint32_t *)tiles_rgba8->dptr, ctx->stream));
+    trc = t.end();
+    if (trc != CLWH_OK) return trc;
+  }
+  touch(tiles_rgba8);
+  return CLWH_OK;
+}
+
+int clwh_frame_from_tiles(clwh_ctx *ctx, clwh_mem *tiles_all, int32_t tile_world, uint32_t width, uint32_t height, clwh_mem *frame) {
+  if (!ctx || !tiles_all || !frame || tile_world < 1) return CLWH_ERR_INVALID_VALUE;
+  if (!is_image(frame, 2, 4, CLWH_ELEM_U8)) return CLWH_ERR_BAD_ARGS;
+  if (width == 0 || height == 0 || (width % 8) || (height % 8)) return CLWH_ERR_BAD_NDRANGE;
+  if ((int64_t)tiles_all->bytes < clwh_accum_len(width, height, tile_world) * 4 * tile_world) return CLWH_ERR_SIZE_MISMATCH;
+  const float zero[3] = {0.0f, 0.0f, 0.0f};
+  RenderArgs a;
+  std::memset(&a, 0, sizeof a);
+  describe_frame(a, (int32_t)width, (int32_t)height, (int32_t)frame->dims[0], (int32_t)frame->dims[1], 0, tile_world, zero, zero);
+  a.frame = (uint32_t *)frame->dptr;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(launch_frame_from_tiles(a, (const uint32_t *)tiles_all->dptr, ctx->stream));
+  touch(frame);
+  return CLWH_OK;
+}
+
 int clwh_ctx_invalidate_derived(clwh_ctx *ctx, int what) {
   if (!ctx) return CLWH_ERR_INVALID_VALUE;
   if (what & CLWH_DERIVED_SCENE) ctx->packed_valid = false;

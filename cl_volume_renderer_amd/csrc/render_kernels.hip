@@ -926,6 +926,40 @@ __global__ __launch_bounds__(64) void k_accum_resolve(const RenderArgs a, const 
   a.frame[(size_t)y * a.frame_w + x] = out;
 }
 
+// The multi-GPU form of the same resolve: a rank resolves ITS tiles to RGBA8 first (tile-major, the slot order of its
+// accumulation buffer), the ranks exchange 4 bytes per pixel instead of 16, and k_frame_from_tiles puts the tiles in place.
+__global__ __launch_bounds__(64) void k_accum_resolve_tiles(const RenderArgs a, const float4 *__restrict__ accum, uint32_t *__restrict__ tiles_out) {
+  const uint32_t slot = blockIdx.x, lane = threadIdx.x;
+  int tx, ty;
+  const bool exists = tile_from_slot(a, slot, tx, ty);  // the last slots of a row may lie beyond the frame
+  const uint32_t x = (uint32_t)tx * 8u + (lane & 7u), y = (uint32_t)ty * 8u + (lane >> 3);
+  uint32_t out = 0u;
+  if (exists && x < (uint32_t)a.frame_w && y < (uint32_t)a.frame_h) {
+    const float4 acc = accum[(size_t)slot * 64u + lane];
+    if (acc.w == 0.0f) {
+      const f3 cam_o = f3{a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]};
+      const f3 cam_d = f3{a.cam_dir[0], a.cam_dir[1], a.cam_dir[2]};
+      const Ray vray = generate_ray(cam_o, cam_d, (int)x, (int)y, a.frame_w, a.frame_h);
+      const uint32_t e = sample_environment_map(a.env, a.env_w, a.env_h, vray.direction);
+      out = (e & 0x00FFFFFFu) | (200u << 24);
+    } else {
+      out = tone_map_rgba8((uint32_t)acc.x, (uint32_t)acc.y, (uint32_t)acc.z, (uint32_t)acc.w);
+    }
+  }
+  tiles_out[(size_t)slot * 64u + lane] = out;
+}
+
+__global__ __launch_bounds__(64) void k_frame_from_tiles(const RenderArgs a, const uint32_t *__restrict__ tiles_all) {
+  const int tx = (int)(blockIdx.x % (unsigned)a.tiles_x), ty = (int)(blockIdx.x / (unsigned)a.tiles_x);
+  const int owner = (tx + ty) % a.tile_world;
+  const size_t slot = (size_t)ty * a.tiles_per_row + (size_t)(tx / a.tile_world);
+  const size_t per_rank = (size_t)a.tiles_y * a.tiles_per_row * 64u;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t x = (uint32_t)tx * 8u + (lane & 7u), y = (uint32_t)ty * 8u + (lane >> 3);
+  if (x >= (uint32_t)a.frame_w || y >= (uint32_t)a.frame_h) return;
+  a.frame[(size_t)y * a.frame_w + x] = tiles_all[(size_t)owner * per_rank + slot * 64u + lane];
+}
+
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_repack(const RepackArgs &a, hipStream_t s) {
   const dim3 grid(((unsigned)a.NBX + 3u) / 4u, (unsigned)a.NBY, (unsigned)a.NBZ);  // every dimension far below the 2^32 work-item limit
@@ -1017,6 +1051,16 @@ hipError_t launch_commit(const RenderArgs &a, hipStream_t s) {
 
 hipError_t launch_resolve(const RenderArgs &a, hipStream_t s) {
   hipLaunchKernelGGL(k_resolve, dim3(a.num_tile_slots), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_accum_resolve_tiles(const RenderArgs &a, const float4 *accum, uint32_t *tiles_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_accum_resolve_tiles, dim3((uint32_t)(a.tiles_y * a.tiles_per_row)), dim3(64), 0, s, a, accum, tiles_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_frame_from_tiles(const RenderArgs &a, const uint32_t *tiles_all, hipStream_t s) {
+  hipLaunchKernelGGL(k_frame_from_tiles, dim3((uint32_t)(a.tiles_x * a.tiles_y)), dim3(64), 0, s, a, tiles_all);
   return hipGetLastError();
 }
 

@@ -103,6 +103,9 @@ _PROTOTYPES = [
     ("clwh_accum_len", C.c_int64, [C.c_uint32, C.c_uint32, C.c_int32]),
     ("clwh_accum_resolve", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p,
                                      C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("clwh_accum_resolve_tiles", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p,
+                                           C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("clwh_frame_from_tiles", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("clwh_ctx_invalidate_derived", C.c_int, [C.c_void_p, C.c_int]),
     ("clwh_sdf_build", C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int32)]),
     ("clwh_buffer_reset", C.c_int, [C.c_void_p, C.c_void_p]),
@@ -299,6 +302,16 @@ class Context:
         d = (C.c_float * 3)(*[float(x) for x in cam_dir])
         _check(lib().clwh_accum_resolve(self.h, accum_all.h, tile_world, width, height, frame.h, env.h, p, d),
                "clwh_accum_resolve")
+
+    def accum_resolve_tiles(self, accum: Mem, tile_rank, tile_world, width, height, tiles_rgba8: Mem, env: Mem, cam_pos, cam_dir):
+        """this rank's tiles -> RGBA8, tile-major (4 bytes per pixel to exchange instead of 16)"""
+        p = (C.c_float * 3)(*[float(x) for x in cam_pos])
+        d = (C.c_float * 3)(*[float(x) for x in cam_dir])
+        _check(lib().clwh_accum_resolve_tiles(self.h, accum.h, tile_rank, tile_world, width, height, tiles_rgba8.h, env.h, p, d),
+               "clwh_accum_resolve_tiles")
+
+    def frame_from_tiles(self, tiles_all: Mem, tile_world, width, height, frame: Mem):
+        _check(lib().clwh_frame_from_tiles(self.h, tiles_all.h, tile_world, width, height, frame.h), "clwh_frame_from_tiles")
 
     def invalidate_derived(self, scene=True, camera=True):
         what = (DERIVED_SCENE if scene else 0) | (DERIVED_CAMERA if camera else 0)

@@ -52,8 +52,10 @@ def unpack_all_ranks(accum_all: np.ndarray, world: int, width: int, height: int)
 
 
 def gather_accum(accum, accum_all, world: int):
-    """The path's only collective: every rank contributes its tile-major float4 buffer, every rank
-    receives all of them back to back.  `accum`, `accum_all`: 1-D torch tensors on the same device."""
+    """The path's only collective: every rank contributes its tile-major buffer, every rank receives all of them back
+    to back.  `accum`, `accum_all`: 1-D torch tensors on the same device -- the float4 sums (16 B per pixel; then
+    `clwh_accum_resolve`), or, as bench.py does it, the rank's tiles already resolved to RGBA8 by
+    `clwh_accum_resolve_tiles` (4 B per pixel; then `clwh_frame_from_tiles`)."""
     if world == 1:
         accum_all.copy_(accum)
         return accum_all

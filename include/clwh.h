@@ -189,6 +189,16 @@ int64_t clwh_accum_len(uint32_t width, uint32_t height, int32_t tile_world);
 int clwh_accum_resolve(clwh_ctx *ctx, clwh_mem *accum_all_ranks, int32_t tile_world, uint32_t width,
                        uint32_t height, clwh_mem *frame_rgba8, clwh_mem *env, const float cam_pos[3],
                        const float cam_dir[3]);
+/* The same resolve for several GPUs with a quarter of the exchange: a rank first resolves ITS tiles to RGBA8
+ * (`tiles_rgba8`: clwh_accum_len(width, height, tile_world) 32-bit pixels, tile-major in the slot order of its accumulation
+ * buffer), the ranks all-gather those 4-byte pixels instead of 16-byte sums, and clwh_frame_from_tiles puts all ranks' tiles,
+ * laid back to back, into the row-major frame.  Pixel for pixel the result of clwh_accum_resolve (the resolve of
+ * ray_marching.cl:82-99 / :172-178 is per pixel). */
+int clwh_accum_resolve_tiles(clwh_ctx *ctx, clwh_mem *accum, int32_t tile_rank, int32_t tile_world, uint32_t width,
+                             uint32_t height, clwh_mem *tiles_rgba8, clwh_mem *env, const float cam_pos[3],
+                             const float cam_dir[3]);
+int clwh_frame_from_tiles(clwh_ctx *ctx, clwh_mem *tiles_all_ranks, int32_t tile_world, uint32_t width, uint32_t height,
+                          clwh_mem *frame_rgba8);
 /* drop what the context derived from its inputs; the next clwh_render rebuilds it.  Needed only when
  * device memory was rewritten behind the shim's back, or to time the rebuild.
  *   CLWH_DERIVED_SCENE   step bytes + hit records (function of volume, SDF, transfer function: flush-time data)

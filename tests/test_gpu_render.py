@@ -167,6 +167,19 @@ def test_image_space_mode_and_tile_partition(gpu_ctx, orc):
         gpu_ctx.accum_resolve(buf, world, w, h, many.frame, many.env, pos, d)
         assert np.array_equal(many.frame.pull(), o.frame)
         buf.release()
+        # what bench.py exchanges instead: every rank resolves ITS tiles to RGBA8 first (4 B per pixel), then the tiles are placed
+        n = ffi.accum_len(w, h, world)
+        parts = []
+        for r in range(world):
+            t = gpu_ctx.buffer(n * 4, np.uint32)
+            gpu_ctx.accum_resolve_tiles(many.accum[r], r, world, w, h, t, many.env, pos, d)
+            parts.append(t.pull(np.uint32))
+            t.release()
+        tiles_all = gpu_ctx.buffer_from(np.concatenate(parts))
+        many.frame.push(np.zeros((h, w, 4), np.uint8))
+        gpu_ctx.frame_from_tiles(tiles_all, world, w, h, many.frame)
+        assert np.array_equal(many.frame.pull(), o.frame)
+        tiles_all.release()
         many.release()
     one.release()
 
