@@ -173,6 +173,7 @@ int clwh_ctx_create_on_stream(int device, void *hip_stream, clwh_ctx **out) {
   if (const char *e = std::getenv("CLWH_TUNE_BLOCKS")) c->tune_bounce_max_blocks = (uint32_t)std::max(1, std::atoi(e));
   if (const char *e = std::getenv("CLWH_TUNE_MACRO_SHIFT")) c->tune_macro_shift = std::atoi(e);
   if (const char *e = std::getenv("CLWH_TUNE_LONG_LAUNCH")) c->tune_force_long_launch = std::atoi(e) != 0;
+  if (const char *e = std::getenv("CLWH_TUNE_SDF")) c->tune_sdf_front = std::strcmp(e, "front") == 0;
   if (const char *e = std::getenv("CLWH_TUNE_CERT")) c->tune_cert_min_step = std::max(0, std::min(127, std::atoi(e)));
   *out = c;
   return CLWH_OK;
@@ -211,6 +212,7 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
   if (ctx->bilateral_weights) (void)hipFree(ctx->bilateral_weights);
   if (ctx->sdf_counters) (void)hipFree(ctx->sdf_counters);
   if (ctx->sdf_flags) (void)hipFree(ctx->sdf_flags);
+  if (ctx->sdf_bits) (void)hipFree(ctx->sdf_bits);
   if (ctx->packed) (void)hipFree(ctx->packed);
   if (ctx->handoff_event) (void)hipEventDestroy(ctx->handoff_event);
   for (hipEvent_t e : ctx->ev_begin) (void)hipEventDestroy(e);
@@ -944,6 +946,98 @@ static int sdf_max_iterations(const clwh_mem *v) {
   return (int)std::min<size_t>(m, 127);
 }
 
+// the byte front: one launch per layer over the active 8x8x8 tiles (sdf_kernels.hip); CLWH_TUNE_SDF=front
+static int sdf_build_front(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settled) {
+  const int X = b.X, Y = b.Y, Z = b.Z;
+  const int kSlots = (int)settled.size();
+  int rc;
+  const int TX = (X + 7) / 8, TY = (Y + 7) / 8, TZ = (Z + 7) / 8;
+  const size_t n_tiles = (size_t)TX * TY * TZ;
+  rc = grow(ctx, (void **)&ctx->sdf_flags, &ctx->sdf_flags_bytes, 4 * n_tiles);
+  if (rc != CLWH_OK) return rc;
+  HIP_TRY(hipMemsetAsync(ctx->sdf_flags, 0, 4 * n_tiles, ctx->stream));
+  uint8_t *flags[3] = {ctx->sdf_flags, ctx->sdf_flags + n_tiles, ctx->sdf_flags + 2 * n_tiles};
+  HIP_TRY(launch_sdf_base_front(b, flags[1], TX, TY, ctx->stream));  // layer 1 reads flags[1 % 3]
+
+  SdfFrontArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.sdf = b.ping;
+  a.X = X; a.Y = Y; a.Z = Z;
+  a.TX = TX; a.TY = TY; a.TZ = TZ;
+  a.max_iterations = b.max_iterations;
+  a.counters = ctx->sdf_counters;
+  a.tile_done = ctx->sdf_flags + 3 * n_tiles;
+
+  // layers that can still settle a voxel: i + 1 < max_iterations; the host looks at the per-layer
+  // counts every kSdfLayersPerCheck launches and stops once a layer settled nothing (nothing can change after it)
+#ifndef CLVR_SDF_LAYERS_PER_CHECK
+#define CLVR_SDF_LAYERS_PER_CHECK 32  // measured 16 / 32 / 64 / 128: 5.31 / 5.21 / 5.14 / 5.19 ms for the 512^3 build
+#endif
+  constexpr int kSdfLayersPerCheck = CLVR_SDF_LAYERS_PER_CHECK;
+  const int last_layer = a.max_iterations - 2;
+  int i = 1;
+  bool quiet = false;
+  while (i <= last_layer && !quiet) {
+    const int chunk_end = std::min(last_layer, i + kSdfLayersPerCheck - 1);
+    for (; i <= chunk_end; ++i) {
+      a.iteration = i;
+      a.flags_cur = flags[i % 3];
+      a.flags_next = flags[(i + 1) % 3];
+      a.flags_clear = flags[(i + 2) % 3];
+      HIP_TRY(launch_sdf_front(a, ctx->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(settled.data(), ctx->sdf_counters, kSlots * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int j = 1; j < i; ++j)
+      if (settled[j] == 0) quiet = true;
+  }
+  if (i <= 1) {  // no layer ran (max_iterations <= 2): still need the base counts
+    HIP_TRY(hipMemcpyAsync(settled.data(), ctx->sdf_counters, kSlots * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  return CLWH_OK;
+}
+
+// the bit-parallel build: event bits -> seeds + base image -> eight layers per launch on one bit per voxel (sdf_kernels.hip)
+static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settled) {
+  const int X = b.X, Y = b.Y, Z = b.Z;
+  const int kSlots = (int)settled.size();
+  SdfBitArgs a;
+  std::memset(&a, 0, sizeof a);
+  a.X = X; a.Y = Y; a.Z = Z;
+  a.WP = 2 * ((X + 63) / 64);
+  a.BX = (X + 63) / 64; a.BY = (Y + 15) / 16; a.BZ = (Z + 15) / 16;
+  const size_t words = (size_t)a.WP * (size_t)Y * (size_t)Z;
+  const size_t n_blocks = (size_t)a.BX * a.BY * a.BZ;
+  if (n_blocks >= (1ull << 31)) return CLWH_ERR_INVALID_VALUE;
+  int rc = grow(ctx, (void **)&ctx->sdf_bits, &ctx->sdf_bits_bytes, 3 * words * sizeof(uint32_t) + n_blocks);
+  if (rc != CLWH_OK) return rc;
+  uint32_t *ev = ctx->sdf_bits, *reached[2] = {ctx->sdf_bits + words, ctx->sdf_bits + 2 * words};
+  a.sdf = b.ping;
+  a.ev = ev;
+  a.state = reinterpret_cast<uint8_t *>(ctx->sdf_bits + 3 * words);
+  a.presence = ctx->sdf_counters;
+  HIP_TRY(hipMemsetAsync(reached[1], 0, words * sizeof(uint32_t), ctx->stream));  // rows nobody ever writes must read as empty in both buffers
+  HIP_TRY(launch_sdfbit_events(b, ev, a.WP, ctx->stream));
+  a.r_out = reached[0];
+  HIP_TRY(launch_sdfbit_seed_init(a, b.max_iterations, ctx->stream));
+  a.r_in = reached[0];
+  HIP_TRY(launch_sdfbit_state(a, ctx->stream));
+  // a voxel D corner moves from the nearest seed settles to D + 1 while D + 1 < max_iterations: max_iterations - 2 layers
+  const int total = b.max_iterations - 2;
+  int t = 0;
+  for (int r0 = 0; r0 < total; r0 += 8, ++t) {
+    a.r0 = r0;
+    a.steps = std::min(8, total - r0);
+    a.r_in = reached[t & 1];
+    a.r_out = reached[(t + 1) & 1];
+    HIP_TRY(launch_sdfbit_layers(a, ctx->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(settled.data(), ctx->sdf_counters, kSlots * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return CLWH_OK;
+}
+
 int clwh_sdf_build(clwh_ctx *ctx, clwh_mem *volume, const char *tf_source, clwh_mem *sdf, int32_t *n_launches) {
   if (!ctx || !volume || !tf_source || !sdf) return CLWH_ERR_INVALID_VALUE;
   if (!is_image(volume, 3, 1, CLWH_ELEM_S16) || !is_image(sdf, 3, 1, CLWH_ELEM_S8)) return CLWH_ERR_BAD_ARGS;
@@ -965,74 +1059,36 @@ int clwh_sdf_build(clwh_ctx *ctx, clwh_mem *volume, const char *tf_source, clwh_
   if (rc != CLWH_OK) return rc;
 
   const int X = (int)volume->dims[0], Y = (int)volume->dims[1], Z = (int)volume->dims[2];
-  const int TX = (X + 7) / 8, TY = (Y + 7) / 8, TZ = (Z + 7) / 8;
-  const size_t n_tiles = (size_t)TX * TY * TZ;
-  rc = grow(ctx, (void **)&ctx->sdf_flags, &ctx->sdf_flags_bytes, 4 * n_tiles);
-  if (rc != CLWH_OK) return rc;
   constexpr int kSlots = 160;
   if (!ctx->sdf_counters) HIP_TRY(hipMalloc((void **)&ctx->sdf_counters, kSlots * sizeof(int32_t)));
   HIP_TRY(hipMemsetAsync(ctx->sdf_counters, 0, kSlots * sizeof(int32_t), ctx->stream));
-  HIP_TRY(hipMemsetAsync(ctx->sdf_flags, 0, 4 * n_tiles, ctx->stream));
-
+  std::vector<int32_t> settled(kSlots, 0);
+  const int max_iterations = sdf_max_iterations(volume);
   SdfArgs b;
   std::memset(&b, 0, sizeof b);
   b.volume = (const int16_t *)volume->dptr;
   b.X = X; b.Y = Y; b.Z = Z;
   b.ping = (int8_t *)sdf->dptr;
-  b.max_iterations = sdf_max_iterations(volume);
+  b.max_iterations = max_iterations;
   b.counters = ctx->sdf_counters;  // [0] != 0: some |v| == 1
   b.tf = tfdev;
   b.cls_in = cls_in;
-  uint8_t *flags[3] = {ctx->sdf_flags, ctx->sdf_flags + n_tiles, ctx->sdf_flags + 2 * n_tiles};
-  HIP_TRY(launch_sdf_base_front(b, flags[1], TX, TY, ctx->stream));  // layer 1 reads flags[1 % 3]
-
-  SdfFrontArgs a;
-  std::memset(&a, 0, sizeof a);
-  a.sdf = (int8_t *)sdf->dptr;
-  a.X = X; a.Y = Y; a.Z = Z;
-  a.TX = TX; a.TY = TY; a.TZ = TZ;
-  a.max_iterations = b.max_iterations;
-  a.counters = ctx->sdf_counters;
-  a.tile_done = ctx->sdf_flags + 3 * n_tiles;
-
-  // layers that can still settle a voxel: i + 1 < max_iterations; the host looks at the per-layer
-  // counts every kSdfLayersPerCheck launches and stops once a layer settled nothing (nothing can change after it)
-#ifndef CLVR_SDF_LAYERS_PER_CHECK
-#define CLVR_SDF_LAYERS_PER_CHECK 32  // measured 16 / 32 / 64 / 128: 5.31 / 5.21 / 5.14 / 5.19 ms for the 512^3 build
-#endif
-  constexpr int kSdfLayersPerCheck = CLVR_SDF_LAYERS_PER_CHECK;
-  const int last_layer = a.max_iterations - 2;
-  std::vector<int32_t> settled(kSlots, 0);
-  int i = 1;
-  bool quiet = false;
-  while (i <= last_layer && !quiet) {
-    const int chunk_end = std::min(last_layer, i + kSdfLayersPerCheck - 1);
-    for (; i <= chunk_end; ++i) {
-      a.iteration = i;
-      a.flags_cur = flags[i % 3];
-      a.flags_next = flags[(i + 1) % 3];
-      a.flags_clear = flags[(i + 2) % 3];
-      HIP_TRY(launch_sdf_front(a, ctx->stream));
-    }
-    HIP_TRY(hipMemcpyAsync(settled.data(), ctx->sdf_counters, kSlots * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int j = 1; j < i; ++j)
-      if (settled[j] == 0) quiet = true;
+  if (ctx->tune_sdf_front) {
+    rc = sdf_build_front(ctx, b, settled);
+  } else {
+    rc = sdf_build_bits(ctx, b, settled);
   }
-  if (i <= 1) {  // no layer ran (max_iterations <= 2): still need the base counts
-    HIP_TRY(hipMemcpyAsync(settled.data(), ctx->sdf_counters, kSlots * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-  }
+  if (rc != CLWH_OK) return rc;
   if (n_launches) {
     // what the reference's host loop would have run (app/signed_distance_field.cpp:22-32): its counter at
     // layer i counts the voxels holding i plus those settling to i+1 (< max); it stops at the first odd
     // layer whose counter is zero, or at the bound
-    const int bound = a.max_iterations + (a.max_iterations % 2) + 1;
+    const int bound = max_iterations + (max_iterations % 2) + 1;
     int launches = bound;
     for (int j = 1; j <= bound; ++j) {
       const int64_t holding = (j == 1) ? settled[0] : (j - 1 < kSlots ? settled[j - 1] : 0);
       const int64_t settling = j < kSlots ? settled[j] : 0;
-      const bool holding_counts = j < a.max_iterations;  // a voxel holding j is rewritten only while j < max
+      const bool holding_counts = j < max_iterations;  // a voxel holding j is rewritten only while j < max
       if ((j & 1) && (holding_counts ? holding : 0) + settling == 0) {
         launches = j;
         break;

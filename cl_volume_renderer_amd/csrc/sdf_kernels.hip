@@ -403,4 +403,301 @@ hipError_t launch_sdf_layer(const SdfArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bit-parallel fused build (clwh_sdf_build, default).  The layer iteration is a breadth-first search over the
+// "8 clamped corner neighbours" graph (above): with D(v) = the number of corner moves from v to the nearest
+// non-homogeneous voxel, the converged image holds sign * min(D + 1, max_iterations), and a voxel only settles
+// while D + 1 < max_iterations.  The search front does not need the byte image at all: the set
+// R_r = {v : D(v) <= r} is ONE BIT per voxel (x-fastest rows of 32-bit words), and one layer is
+//   R_{r+1} = R_r | shift_x(+-1, clamped)( R_r(y-1,z-1) | R_r(y+1,z-1) | R_r(y-1,z+1) | R_r(y+1,z+1) )   (rows clamped)
+// -- a dozen word operations for 128 voxels.  A block keeps a 128 x 32 x 32 voxel region of R (its 64 x 16 x 16 core and a
+// halo of 8 rows / 32 bits) in 16 KB of LDS and runs EIGHT layers on it before anything returns to memory: information
+// travels one voxel per layer, so after 8 layers the core is exact although the halo's rim is not.  125 dependent
+// launches become 16, none of them with a host round trip; blocks whose core is complete, or whose 27-neighbourhood
+// holds no reached voxel yet, leave after reading a few state bytes.  A voxel's value is written once, in the launch
+// in which its bit appears (layer index recorded bit-sliced per core word), with the sign of its event bit.
+// Bit-exact against the oracle / the reference's golden vector like the byte front it replaces (tests/test_gpu_sdf.py).
+
+// event bit of every voxel: one wave = 64 voxels along x = two words
+template <bool USE_GRAD>
+__global__ __launch_bounds__(256) void k_sdfbit_events(const SdfArgs a, uint32_t *__restrict__ ev, int32_t WP) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const int y = blockIdx.y, z = blockIdx.z;
+  const VolumeIntLinear v{a.volume, a.X, a.Y, a.Z};
+  bool e = false;
+  if (x < a.X) e = event_at<USE_GRAD>(v, a.tf, a.cls_in, x, y, z);
+  const unsigned long long m = __ballot(e);
+  if ((threadIdx.x & 63u) == 0u) {
+    const int w = x >> 5;  // x is a multiple of 64 here
+    if (w < WP) {
+      uint32_t *row = ev + ((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)WP;
+      row[w] = (uint32_t)m;
+      row[w + 1] = (uint32_t)(m >> 32);  // WP is even
+    }
+  }
+}
+
+// bits of a row shifted to x - 1 and x + 1 with the reference's clamp (signed_distance_field.cl:72): the neighbour of
+// x = 0 at x - 1 is x = 0 itself, the neighbour of x = X - 1 at x + 1 is itself -- `both` = bits at either neighbour
+__device__ __forceinline__ uint32_t sdfbit_x_neighbours(uint32_t prev, uint32_t cur, uint32_t next, uint32_t clampfix) {
+  return ((cur << 1) | (prev >> 31)) | ((cur >> 1) | (next << 31)) | (cur & clampfix);
+}
+
+// non-homogeneous voxels (create_base_image: some clamped corner neighbour's event flag differs) = the seeds R_0
+__global__ __launch_bounds__(256) void k_sdfbit_seed(const uint32_t *__restrict__ ev, uint32_t *__restrict__ r0, int32_t X, int32_t Y,
+                                                      int32_t Z, int32_t WP, int32_t *presence) {
+  const int w = blockIdx.x * 256 + threadIdx.x;
+  const int y = blockIdx.y, z = blockIdx.z;
+  if (w >= WP) return;
+  const int x_lo = w * 32;
+  uint32_t valid = 0u;
+  if (x_lo < X) valid = (X - x_lo >= 32) ? 0xFFFFFFFFu : ((1u << (X - x_lo)) - 1u);
+  const uint32_t lastbit = (((X - 1) >> 5) == w) ? (1u << ((X - 1) & 31)) : 0u;
+  const uint32_t firstbit = (w == 0) ? 1u : 0u;
+  const uint32_t own = ev[((size_t)z * Y + y) * (size_t)WP + w];
+  uint32_t differs = 0u;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int ny = min(max(y + ((c & 1) ? 1 : -1), 0), Y - 1);
+    const int nz = min(max(z + ((c & 2) ? 1 : -1), 0), Z - 1);
+    const uint32_t *row = ev + ((size_t)nz * Y + ny) * (size_t)WP;
+    const uint32_t cur = row[w], prev = w > 0 ? row[w - 1] : 0u, next = w + 1 < WP ? row[w + 1] : 0u;
+    const uint32_t left = ((cur << 1) | (prev >> 31)) | (cur & firstbit);   // value at clamp(x - 1)
+    const uint32_t right = ((cur >> 1) | (next << 31)) | (cur & lastbit);   // value at clamp(x + 1)
+    differs |= (left ^ own) | (right ^ own);
+  }
+  differs &= valid;
+  r0[((size_t)z * Y + y) * (size_t)WP + w] = differs;
+  if (differs) presence[0] = 1;  // non-zero marker, plain store (see k_sdf_base_front)
+}
+
+// base image from the two bit sets: +-1 at a seed, +-max_iterations elsewhere
+__global__ __launch_bounds__(256) void k_sdfbit_init(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ r0, int8_t *__restrict__ sdf,
+                                                      int32_t X, int32_t Y, int32_t Z, int32_t WP, int32_t max_iterations) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const int y = blockIdx.y, z = blockIdx.z;
+  if (x >= X) return;
+  const size_t roww = ((size_t)z * Y + y) * (size_t)WP + (size_t)(x >> 5);
+  const uint32_t e = (ev[roww] >> (x & 31)) & 1u, s = (r0[roww] >> (x & 31)) & 1u;
+  const int val = s ? 1 : max_iterations;
+  sdf[((size_t)z * Y + y) * (size_t)X + (size_t)x] = (int8_t)(e ? -val : val);
+}
+
+constexpr int kBitCoreY = 16, kBitCoreZ = 16, kBitHalo = 8, kBitReg = 32;  // region = core + halo on both sides: 32 x 32 rows of 4 words
+static_assert(kBitCoreY + 2 * kBitHalo == kBitReg && kBitCoreZ + 2 * kBitHalo == kBitReg, "region");
+
+// block state: 0 = no reached voxel in the core, 1 = some, 2 = all (just now: the other bit buffer is not complete yet), 3 = all, both buffers
+__global__ __launch_bounds__(64) void k_sdfbit_state(const SdfBitArgs a) {
+  const int b = blockIdx.x;
+  const int bx = b % a.BX, by = (b / a.BX) % a.BY, bz = b / (a.BX * a.BY);
+  const unsigned lane = threadIdx.x;
+  bool any = false, all = true;
+  for (int r = (int)lane; r < kBitCoreY * kBitCoreZ; r += 64) {
+    const int gy = by * kBitCoreY + (r % kBitCoreY), gz = bz * kBitCoreZ + (r / kBitCoreY);
+    if (gy >= a.Y || gz >= a.Z) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gw = 2 * bx + j, x_lo = gw * 32;
+      if (gw >= a.WP || x_lo >= a.X) continue;
+      const uint32_t valid = (a.X - x_lo >= 32) ? 0xFFFFFFFFu : ((1u << (a.X - x_lo)) - 1u);
+      const uint32_t wv = a.r_in[((size_t)gz * a.Y + gy) * (size_t)a.WP + gw];
+      any |= wv != 0u;
+      all &= wv == valid;
+    }
+  }
+  const bool w_any = __ballot(any) != 0ull, w_all = __ballot(!all) == 0ull;
+  if (lane == 0u) a.state[b] = w_all ? 2 : (w_any ? 1 : 0);
+}
+
+__global__ __launch_bounds__(256) void k_sdfbit_layers(const SdfBitArgs a) {
+  __shared__ __attribute__((aligned(16))) uint32_t s_reg[kBitReg * kBitReg * 4];  // [rz][ry][4 words]; later the bit-sliced results
+  __shared__ uint32_t s_nb_any, s_all, s_any, s_steps;
+  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const int bx = b % a.BX, by = (b / a.BX) % a.BY, bz = b / (a.BX * a.BY);
+  const uint8_t own_state = a.state[b];
+  if (own_state == 3) return;
+  // this block's core rows / words inside the volume
+  const int ybase = by * kBitCoreY - kBitHalo, zbase = bz * kBitCoreZ - kBitHalo;
+  uint32_t valid[4], clampfix[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int gw = 2 * bx - 1 + j, x_lo = gw * 32;
+    valid[j] = 0u;
+    clampfix[j] = 0u;
+    if (gw >= 0 && gw < a.WP && x_lo < a.X) {
+      valid[j] = (a.X - x_lo >= 32) ? 0xFFFFFFFFu : ((1u << (a.X - x_lo)) - 1u);
+      clampfix[j] = (gw == 0 ? 1u : 0u) | ((((a.X - 1) >> 5) == gw) ? (1u << ((a.X - 1) & 31)) : 0u);
+    }
+  }
+  if (own_state == 2) {
+    // complete since the previous launch: bring the other buffer up to date, then never come back
+    for (int r = (int)tid; r < kBitCoreY * kBitCoreZ; r += 256) {
+      const int gy = by * kBitCoreY + (r % kBitCoreY), gz = bz * kBitCoreZ + (r / kBitCoreY);
+      if (gy >= a.Y || gz >= a.Z) continue;
+#pragma unroll
+      for (int j = 1; j <= 2; ++j) {
+        const int gw = 2 * bx - 1 + j;
+        if (gw < a.WP) a.r_out[((size_t)gz * a.Y + gy) * (size_t)a.WP + gw] = valid[j];
+      }
+    }
+    if (tid == 0u) a.state[b] = 3;
+    return;
+  }
+  if (tid == 0u) { s_nb_any = 0u; s_all = 1u; s_any = 0u; s_steps = 0u; }
+  __syncthreads();
+  if (tid < 27u) {
+    const int nx = bx + (int)(tid % 3u) - 1, ny = by + (int)((tid / 3u) % 3u) - 1, nz = bz + (int)(tid / 9u) - 1;
+    if (nx >= 0 && ny >= 0 && nz >= 0 && nx < a.BX && ny < a.BY && nz < a.BZ && a.state[((size_t)nz * a.BY + ny) * a.BX + nx] != 0) s_nb_any = 1u;
+  }
+  __syncthreads();
+  if (s_nb_any == 0u) return;  // nothing within reach of the core yet: both buffers hold its (empty) rows
+
+  // region rows of this thread: r = tid + 256 i  ->  ry = r & 31, rz = r >> 5
+  uint4 cur[4];
+  bool in_vol[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (int)tid + 256 * i, ry = r & 31, rz = r >> 5;
+    const int gy = ybase + ry, gz = zbase + rz;
+    in_vol[i] = gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if (in_vol[i]) {
+      const uint32_t *row = a.r_in + ((size_t)gz * a.Y + gy) * (size_t)a.WP;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gw = 2 * bx - 1 + j;
+        if (gw >= 0 && gw < a.WP) w[j] = row[gw];
+      }
+    }
+    cur[i] = uint4{w[0], w[1], w[2], w[3]};
+    *reinterpret_cast<uint4 *>(&s_reg[r * 4]) = cur[i];
+  }
+  __syncthreads();
+
+  // core rows of this thread are i = 1, 2 when ry lies in [8, 24): newly reached bits and their layer, bit-sliced
+  const bool has_core = ((tid & 31u) >= (unsigned)kBitHalo) && ((tid & 31u) < (unsigned)(kBitHalo + kBitCoreY));
+  uint32_t rec_any[2][2] = {{0u, 0u}, {0u, 0u}}, rec_b0[2][2] = {{0u, 0u}, {0u, 0u}}, rec_b1[2][2] = {{0u, 0u}, {0u, 0u}},
+           rec_b2[2][2] = {{0u, 0u}, {0u, 0u}};
+  uint32_t step_mask = 0u;
+  for (int k = 0; k < a.steps; ++k) {
+    uint4 nxt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      nxt[i] = cur[i];
+      if (!in_vol[i]) continue;
+      const int r = (int)tid + 256 * i, ry = r & 31, rz = r >> 5;
+      const int gy = ybase + ry, gz = zbase + rz;
+      // neighbour rows: clamped to the volume first (the reference's clamp), then to the region (rim rows: never reach the core)
+      const int y0 = min(max(max(gy - 1, 0) - ybase, 0), kBitReg - 1), y1 = min(max(min(gy + 1, a.Y - 1) - ybase, 0), kBitReg - 1);
+      const int z0 = min(max(max(gz - 1, 0) - zbase, 0), kBitReg - 1), z1 = min(max(min(gz + 1, a.Z - 1) - zbase, 0), kBitReg - 1);
+      const uint4 n00 = *reinterpret_cast<const uint4 *>(&s_reg[(z0 * kBitReg + y0) * 4]);
+      const uint4 n10 = *reinterpret_cast<const uint4 *>(&s_reg[(z0 * kBitReg + y1) * 4]);
+      const uint4 n01 = *reinterpret_cast<const uint4 *>(&s_reg[(z1 * kBitReg + y0) * 4]);
+      const uint4 n11 = *reinterpret_cast<const uint4 *>(&s_reg[(z1 * kBitReg + y1) * 4]);
+      const uint32_t u0 = n00.x | n10.x | n01.x | n11.x, u1 = n00.y | n10.y | n01.y | n11.y, u2 = n00.z | n10.z | n01.z | n11.z,
+                     u3 = n00.w | n10.w | n01.w | n11.w;
+      nxt[i].x |= sdfbit_x_neighbours(0u, u0, u1, clampfix[0]) & valid[0];
+      nxt[i].y |= sdfbit_x_neighbours(u0, u1, u2, clampfix[1]) & valid[1];
+      nxt[i].z |= sdfbit_x_neighbours(u1, u2, u3, clampfix[2]) & valid[2];
+      nxt[i].w |= sdfbit_x_neighbours(u2, u3, 0u, clampfix[3]) & valid[3];
+    }
+    if (has_core) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint32_t nb0 = nxt[c + 1].y & ~cur[c + 1].y, nb1 = nxt[c + 1].z & ~cur[c + 1].z;
+        rec_any[c][0] |= nb0; rec_any[c][1] |= nb1;
+        if (k & 1) { rec_b0[c][0] |= nb0; rec_b0[c][1] |= nb1; }
+        if (k & 2) { rec_b1[c][0] |= nb0; rec_b1[c][1] |= nb1; }
+        if (k & 4) { rec_b2[c][0] |= nb0; rec_b2[c][1] |= nb1; }
+        if (nb0 | nb1) step_mask |= 1u << k;
+      }
+    }
+    __syncthreads();  // everybody has read layer k
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      cur[i] = nxt[i];
+      *reinterpret_cast<uint4 *>(&s_reg[((int)tid + 256 * i) * 4]) = cur[i];
+    }
+    __syncthreads();
+  }
+
+  // core rows back to the other bit buffer; the block's state for the next launch
+  bool any = false, all = true;
+  if (has_core) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int i = c + 1;
+      if (!in_vol[i]) continue;
+      const int r = (int)tid + 256 * i, ry = r & 31, rz = r >> 5;
+      uint32_t *row = a.r_out + ((size_t)(zbase + rz) * a.Y + (ybase + ry)) * (size_t)a.WP;
+      const uint32_t w1 = cur[i].y, w2 = cur[i].z;
+      const int gw = 2 * bx;
+      if (gw < a.WP) { row[gw] = w1; any |= w1 != 0u; all &= w1 == valid[1]; }
+      if (gw + 1 < a.WP) { row[gw + 1] = w2; any |= w2 != 0u; all &= w2 == valid[2]; }
+    }
+  }
+  if (any) s_any = 1u;
+  if (!all) s_all = 0u;
+  if (step_mask) atomicOr(&s_steps, step_mask);
+  __syncthreads();  // also: nobody reads the region any more
+  if (tid == 0u) {
+    a.state[b] = s_all ? 2 : (s_any ? 1 : 0);
+    for (uint32_t m = s_steps; m; m &= m - 1u) a.presence[a.r0 + __ffs((int)m)] = 1;  // layer r0 + k + 1 settled something
+  }
+  if (s_steps == 0u) return;
+
+  // values: the region's LDS now holds {new bits, layer bit 0, 1, 2} x 2 words per core row; lane = voxel
+  if (has_core) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int r = (int)tid + 256 * (c + 1), ry = r & 31, rz = r >> 5;
+      uint32_t *o = &s_reg[(((rz - kBitHalo) * kBitCoreY) + (ry - kBitHalo)) * 8];
+      o[0] = rec_any[c][0]; o[1] = rec_any[c][1]; o[2] = rec_b0[c][0]; o[3] = rec_b0[c][1];
+      o[4] = rec_b1[c][0]; o[5] = rec_b1[c][1]; o[6] = rec_b2[c][0]; o[7] = rec_b2[c][1];
+    }
+  }
+  __syncthreads();
+  const int x = bx * 64 + (int)lane;
+  const unsigned j = lane >> 5, bit = lane & 31u;
+  for (int q = 0; q < (kBitCoreY * kBitCoreZ) / 4; ++q) {
+    const int cr = (int)wave * ((kBitCoreY * kBitCoreZ) / 4) + q;  // core row: cy = cr % 16, cz = cr / 16
+    const uint32_t *o = &s_reg[cr * 8];
+    if ((o[0] | o[1]) == 0u) continue;  // wave-uniform
+    if (((o[j] >> bit) & 1u) == 0u) continue;
+    const int gy = by * kBitCoreY + (cr % kBitCoreY), gz = bz * kBitCoreZ + (cr / kBitCoreY);
+    const int k = (int)((o[2 + j] >> bit) & 1u) | ((int)((o[4 + j] >> bit) & 1u) << 1) | ((int)((o[6 + j] >> bit) & 1u) << 2);
+    const int val = a.r0 + k + 2;  // D = r0 + k + 1, value D + 1
+    const uint32_t e = (a.ev[((size_t)gz * a.Y + gy) * (size_t)a.WP + (size_t)(x >> 5)] >> (x & 31)) & 1u;
+    a.sdf[((size_t)gz * a.Y + gy) * (size_t)a.X + (size_t)x] = (int8_t)(e ? -val : val);
+  }
+}
+
+hipError_t launch_sdfbit_events(const SdfArgs &a, uint32_t *ev, int32_t WP, hipStream_t s) {
+  const dim3 grid(((unsigned)a.X + 255u) / 256u, (unsigned)a.Y, (unsigned)a.Z);
+  if (a.tf.uses_gradient)
+    hipLaunchKernelGGL(k_sdfbit_events<true>, grid, dim3(256), 0, s, a, ev, WP);
+  else
+    hipLaunchKernelGGL(k_sdfbit_events<false>, grid, dim3(256), 0, s, a, ev, WP);
+  return hipGetLastError();
+}
+
+hipError_t launch_sdfbit_seed_init(const SdfBitArgs &a, int32_t max_iterations, hipStream_t s) {
+  hipLaunchKernelGGL(k_sdfbit_seed, dim3(((unsigned)a.WP + 255u) / 256u, (unsigned)a.Y, (unsigned)a.Z), dim3(256), 0, s, a.ev, a.r_out, a.X, a.Y, a.Z,
+                     a.WP, a.presence);
+  hipLaunchKernelGGL(k_sdfbit_init, dim3(((unsigned)a.X + 255u) / 256u, (unsigned)a.Y, (unsigned)a.Z), dim3(256), 0, s, a.ev, (const uint32_t *)a.r_out,
+                     a.sdf, a.X, a.Y, a.Z, a.WP, max_iterations);
+  return hipGetLastError();
+}
+
+hipError_t launch_sdfbit_state(const SdfBitArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(k_sdfbit_state, dim3((unsigned)(a.BX * a.BY * a.BZ)), dim3(64), 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_sdfbit_layers(const SdfBitArgs &a, hipStream_t s) {
+  hipLaunchKernelGGL(k_sdfbit_layers, dim3((unsigned)(a.BX * a.BY * a.BZ)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 }  // namespace clvr
