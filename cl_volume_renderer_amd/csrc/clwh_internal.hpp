@@ -179,16 +179,20 @@ struct SdfBitArgs {
   const uint32_t *ev;      // event bit per voxel, rows of WP 32-bit words
   const uint32_t *r_in;    // reached set after r0 layers
   uint32_t *r_out;         // reached set after r0 + steps layers (core rows of the active blocks)
-  uint8_t *state;          // per 64 x 16 x 16 block: 0 empty, 1 some, 2 complete (just now), 3 complete in both buffers
+  uint8_t *state;          // per block of sdfbit_block_grid: 0 empty, 1 some, 2 complete (just now), 3 complete in both buffers
   int32_t *presence;       // [D] != 0: some voxel lies D corner moves from the nearest seed; [0]: a seed exists
   int32_t X, Y, Z, WP;
-  int32_t BX, BY, BZ;
+  int32_t BX, BY, BZ, core_z;  // blocks of 64 x 48 x core_z voxels (sdfbit_block_grid)
   int32_t r0, steps;       // steps <= 8
+  uint32_t *list;          // blocks that can change in this launch (k_sdfbit_list)
+  uint32_t *list_count;    // their number; list_head: the persistent grid's queue position
+  uint32_t *list_head;
 };
+void sdfbit_block_grid(int X, int Y, int Z, int waves, int32_t *BX, int32_t *BY, int32_t *BZ, int32_t *core_z);  // blocks of 64 x 48 x (4 waves - 16) voxels
 hipError_t launch_sdfbit_events(const SdfArgs &a, uint32_t *ev, int32_t WP, hipStream_t s);
 hipError_t launch_sdfbit_seed_init(const SdfBitArgs &a, int32_t max_iterations, hipStream_t s);  // seeds into a.r_out, base image into a.sdf
 hipError_t launch_sdfbit_state(const SdfBitArgs &a, hipStream_t s);                              // block states of a.r_in
-hipError_t launch_sdfbit_layers(const SdfBitArgs &a, hipStream_t s);
+hipError_t launch_sdfbit_layers(const SdfBitArgs &a, int waves, unsigned grid_blocks, hipStream_t s);
 
 hipError_t launch_sdf_base(const SdfArgs &a, hipStream_t s);
 hipError_t launch_sdf_base_front(const SdfArgs &a, uint8_t *flags, int32_t TX, int32_t TY, hipStream_t s);
@@ -266,6 +270,8 @@ struct clwh_ctx {
   size_t sdf_flags_bytes = 0;
   uint32_t *sdf_bits = nullptr;     // bit-parallel build: event bits, two reached-set buffers, block states
   size_t sdf_bits_bytes = 0;
+  int32_t tune_sdfbit_waves = 8;    // CLWH_TUNE_SDFBIT_WAVES: 8 or 16 waves per block of the bit-parallel build
+  int32_t tune_sdfbit_grid = 512;   // CLWH_TUNE_SDFBIT_GRID: its persistent grid
   int32_t tune_sdf_front = 0;       // CLWH_TUNE_SDF=front: the byte-front build (one launch per layer) instead of the bit-parallel one
   // derived packed volume (single entry, keyed by the source objects' identity + version and the TF)
   uint8_t *packed = nullptr;  // hit records (8 B per voxel of the brick grid), the step bytes (1 B), the per-brick minima (4 B per brick), the macro-cell table

@@ -174,6 +174,8 @@ int clwh_ctx_create_on_stream(int device, void *hip_stream, clwh_ctx **out) {
   if (const char *e = std::getenv("CLWH_TUNE_MACRO_SHIFT")) c->tune_macro_shift = std::atoi(e);
   if (const char *e = std::getenv("CLWH_TUNE_LONG_LAUNCH")) c->tune_force_long_launch = std::atoi(e) != 0;
   if (const char *e = std::getenv("CLWH_TUNE_SDF")) c->tune_sdf_front = std::strcmp(e, "front") == 0;
+  if (const char *e = std::getenv("CLWH_TUNE_SDFBIT_WAVES")) c->tune_sdfbit_waves = std::atoi(e) == 16 ? 16 : 8;
+  if (const char *e = std::getenv("CLWH_TUNE_SDFBIT_GRID")) c->tune_sdfbit_grid = std::max(1, std::atoi(e));
   if (const char *e = std::getenv("CLWH_TUNE_CERT")) c->tune_cert_min_step = std::max(0, std::min(127, std::atoi(e)));
   *out = c;
   return CLWH_OK;
@@ -1006,32 +1008,41 @@ static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settl
   std::memset(&a, 0, sizeof a);
   a.X = X; a.Y = Y; a.Z = Z;
   a.WP = 2 * ((X + 63) / 64);
-  a.BX = (X + 63) / 64; a.BY = (Y + 15) / 16; a.BZ = (Z + 15) / 16;
+  const int waves = ctx->tune_sdfbit_waves;
+  sdfbit_block_grid(X, Y, Z, waves, &a.BX, &a.BY, &a.BZ, &a.core_z);
   const size_t words = (size_t)a.WP * (size_t)Y * (size_t)Z;
   const size_t n_blocks = (size_t)a.BX * a.BY * a.BZ;
   if (n_blocks >= (1ull << 31)) return CLWH_ERR_INVALID_VALUE;
-  int rc = grow(ctx, (void **)&ctx->sdf_bits, &ctx->sdf_bits_bytes, 3 * words * sizeof(uint32_t) + n_blocks);
+  // a voxel D corner moves from the nearest seed settles to D + 1 while D + 1 < max_iterations: max_iterations - 2 layers
+  const int total = b.max_iterations - 2;
+  const int n_launches = total > 0 ? (total + 7) / 8 : 0;
+  // scratch: event bits, two reached-set buffers, the list of active blocks, per-launch {count, head}, block states
+  const size_t scratch_words = 3 * words + n_blocks + 2 * (size_t)(n_launches + 1);
+  int rc = grow(ctx, (void **)&ctx->sdf_bits, &ctx->sdf_bits_bytes, scratch_words * sizeof(uint32_t) + n_blocks);
   if (rc != CLWH_OK) return rc;
   uint32_t *ev = ctx->sdf_bits, *reached[2] = {ctx->sdf_bits + words, ctx->sdf_bits + 2 * words};
+  uint32_t *list = ctx->sdf_bits + 3 * words, *queue = list + n_blocks;
   a.sdf = b.ping;
   a.ev = ev;
-  a.state = reinterpret_cast<uint8_t *>(ctx->sdf_bits + 3 * words);
+  a.list = list;
+  a.state = reinterpret_cast<uint8_t *>(ctx->sdf_bits + scratch_words);
   a.presence = ctx->sdf_counters;
   HIP_TRY(hipMemsetAsync(reached[1], 0, words * sizeof(uint32_t), ctx->stream));  // rows nobody ever writes must read as empty in both buffers
+  HIP_TRY(hipMemsetAsync(queue, 0, 2 * (size_t)(n_launches + 1) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(launch_sdfbit_events(b, ev, a.WP, ctx->stream));
   a.r_out = reached[0];
   HIP_TRY(launch_sdfbit_seed_init(a, b.max_iterations, ctx->stream));
   a.r_in = reached[0];
   HIP_TRY(launch_sdfbit_state(a, ctx->stream));
-  // a voxel D corner moves from the nearest seed settles to D + 1 while D + 1 < max_iterations: max_iterations - 2 layers
-  const int total = b.max_iterations - 2;
   int t = 0;
   for (int r0 = 0; r0 < total; r0 += 8, ++t) {
     a.r0 = r0;
     a.steps = std::min(8, total - r0);
     a.r_in = reached[t & 1];
     a.r_out = reached[(t + 1) & 1];
-    HIP_TRY(launch_sdfbit_layers(a, ctx->stream));
+    a.list_count = queue + 2 * t;
+    a.list_head = queue + 2 * t + 1;
+    HIP_TRY(launch_sdfbit_layers(a, waves, (unsigned)ctx->tune_sdfbit_grid * (waves == 16 ? 1u : 2u) / 2u, ctx->stream));
   }
   HIP_TRY(hipMemcpyAsync(settled.data(), ctx->sdf_counters, kSlots * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));

@@ -437,6 +437,47 @@ __global__ __launch_bounds__(256) void k_sdfbit_events(const SdfArgs a, uint32_t
   }
 }
 
+// the same for rule tables without `gradient` on rows of a multiple of 8 voxels: a lane classifies the 8 voxels of one
+// 16-byte load and writes their byte of the bit image (387 -> 75 us at 512^3: the per-voxel kernel was issue-bound)
+// (row, unit) of a thread for kernels that work on `units` items per (y, z) row: blockIdx.x counts groups of rows
+// (rows_per_block = 256 / units when a row has fewer than 256 units), blockIdx.y chunks of 256 units within a row
+__device__ __forceinline__ bool sdfbit_row_unit(uint32_t units, size_t n_rows, size_t &row, uint32_t &unit) {
+  if (units >= 256u) {
+    row = blockIdx.x;
+    unit = blockIdx.y * 256u + threadIdx.x;
+  } else {
+    const uint32_t rows_per_block = 256u / units, r = threadIdx.x / units;
+    row = (size_t)blockIdx.x * rows_per_block + r;
+    unit = threadIdx.x - r * units;
+    if (r >= rows_per_block) return false;
+  }
+  return row < n_rows && unit < units;
+}
+static dim3 sdfbit_row_grid(uint32_t units, size_t n_rows) {
+  if (units >= 256u) return dim3((unsigned)n_rows, (units + 255u) / 256u);
+  const uint32_t rows_per_block = 256u / units;
+  return dim3((unsigned)((n_rows + rows_per_block - 1u) / rows_per_block), 1u);
+}
+
+__global__ __launch_bounds__(256) void k_sdfbit_events8(const SdfArgs a, uint8_t *__restrict__ ev_bytes, int32_t WP) {
+  size_t row;
+  uint32_t unit;
+  if (!sdfbit_row_unit((uint32_t)WP * 4u, (size_t)a.Y * (size_t)a.Z, row, unit)) return;
+  const int x0 = (int)unit * 8;
+  uint32_t bits = 0u;
+  if (x0 < a.X) {  // X is a multiple of 8: all eight voxels exist
+    const uint4 q = *reinterpret_cast<const uint4 *>(a.volume + row * (size_t)a.X + (size_t)x0);
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+      uint32_t color = 0u;
+      const int value = (int)(int16_t)(w[h >> 1] >> (16 * (h & 1)));
+      bits |= tf_eval(a.tf, value, 0, color) ? (1u << h) : 0u;
+    }
+  }
+  ev_bytes[row * (size_t)WP * 4u + unit] = (uint8_t)bits;
+}
+
 // bits of a row shifted to x - 1 and x + 1 with the reference's clamp (signed_distance_field.cl:72): the neighbour of
 // x = 0 at x - 1 is x = 0 itself, the neighbour of x = X - 1 at x + 1 is itself -- `both` = bits at either neighbour
 __device__ __forceinline__ uint32_t sdfbit_x_neighbours(uint32_t prev, uint32_t cur, uint32_t next, uint32_t clampfix) {
@@ -446,15 +487,17 @@ __device__ __forceinline__ uint32_t sdfbit_x_neighbours(uint32_t prev, uint32_t 
 // non-homogeneous voxels (create_base_image: some clamped corner neighbour's event flag differs) = the seeds R_0
 __global__ __launch_bounds__(256) void k_sdfbit_seed(const uint32_t *__restrict__ ev, uint32_t *__restrict__ r0, int32_t X, int32_t Y,
                                                       int32_t Z, int32_t WP, int32_t *presence) {
-  const int w = blockIdx.x * 256 + threadIdx.x;
-  const int y = blockIdx.y, z = blockIdx.z;
-  if (w >= WP) return;
+  size_t rowi;
+  uint32_t unit;
+  if (!sdfbit_row_unit((uint32_t)WP, (size_t)Y * (size_t)Z, rowi, unit)) return;
+  const int w = (int)unit;
+  const int z = (int)(rowi / (size_t)Y), y = (int)(rowi - (size_t)z * (size_t)Y);
   const int x_lo = w * 32;
   uint32_t valid = 0u;
   if (x_lo < X) valid = (X - x_lo >= 32) ? 0xFFFFFFFFu : ((1u << (X - x_lo)) - 1u);
   const uint32_t lastbit = (((X - 1) >> 5) == w) ? (1u << ((X - 1) & 31)) : 0u;
   const uint32_t firstbit = (w == 0) ? 1u : 0u;
-  const uint32_t own = ev[((size_t)z * Y + y) * (size_t)WP + w];
+  const uint32_t own = ev[rowi * (size_t)WP + w];
   uint32_t differs = 0u;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -467,7 +510,7 @@ __global__ __launch_bounds__(256) void k_sdfbit_seed(const uint32_t *__restrict_
     differs |= (left ^ own) | (right ^ own);
   }
   differs &= valid;
-  r0[((size_t)z * Y + y) * (size_t)WP + w] = differs;
+  r0[rowi * (size_t)WP + w] = differs;
   if (differs) presence[0] = 1;  // non-zero marker, plain store (see k_sdf_base_front)
 }
 
@@ -483,8 +526,30 @@ __global__ __launch_bounds__(256) void k_sdfbit_init(const uint32_t *__restrict_
   sdf[((size_t)z * Y + y) * (size_t)X + (size_t)x] = (int8_t)(e ? -val : val);
 }
 
-constexpr int kBitCoreY = 16, kBitCoreZ = 16, kBitHalo = 8, kBitReg = 32;  // region = core + halo on both sides: 32 x 32 rows of 4 words
-static_assert(kBitCoreY + 2 * kBitHalo == kBitReg && kBitCoreZ + 2 * kBitHalo == kBitReg, "region");
+// the same, sixteen voxels (one 16-byte store) per lane: rows of a multiple of 16 voxels, max_iterations >= 1
+__global__ __launch_bounds__(256) void k_sdfbit_init16(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ r0, int8_t *__restrict__ sdf,
+                                                        int32_t X, int32_t Y, int32_t Z, int32_t WP, int32_t max_iterations) {
+  size_t row;
+  uint32_t unit;
+  if (!sdfbit_row_unit((uint32_t)(X / 16), (size_t)Y * (size_t)Z, row, unit)) return;
+  const uint32_t b1 = 0x01010101u, mb = (uint32_t)max_iterations * b1, dm = (uint32_t)(max_iterations - 1);
+  const int x0 = (int)unit * 16;
+  const size_t wi = row * (size_t)WP + (size_t)(x0 >> 5);
+  const uint32_t e16 = (ev[wi] >> (x0 & 31)) & 0xFFFFu, s16 = (r0[wi] >> (x0 & 31)) & 0xFFFFu;
+  uint32_t out[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    // four bits -> four bytes of 0 / 1
+    const uint32_t sb = (((s16 >> (4 * q)) & 0xFu) * 0x00204081u) & b1, eb = (((e16 >> (4 * q)) & 0xFu) * 0x00204081u) & b1;
+    const uint32_t val = mb - sb * dm;               // per byte: seed ? 1 : max_iterations (1..127, no borrow between bytes)
+    const uint32_t neg = eb * 0xFFu;                  // 0xFF where the voxel is an event
+    out[q] = (val ^ neg) + eb;                        // two's complement per byte: 255 - v + 1 <= 255, no carry
+  }
+  *reinterpret_cast<uint4 *>(sdf + row * (size_t)X + (size_t)x0) = uint4{out[0], out[1], out[2], out[3]};
+}
+
+constexpr int kBitCoreY = 48, kBitHalo = 8, kBitRows = 4;  // a wave = 64 rows along y (48 core + 2 x 8 halo) x 4 rows along z
+// a block = NW waves (8 or 16) = NW strips of 4 z-rows: region z = 4 NW, core z = 4 NW - 16 (SdfBitArgs::core_z)
 
 // block state: 0 = no reached voxel in the core, 1 = some, 2 = all (just now: the other bit buffer is not complete yet), 3 = all, both buffers
 __global__ __launch_bounds__(64) void k_sdfbit_state(const SdfBitArgs a) {
@@ -492,8 +557,8 @@ __global__ __launch_bounds__(64) void k_sdfbit_state(const SdfBitArgs a) {
   const int bx = b % a.BX, by = (b / a.BX) % a.BY, bz = b / (a.BX * a.BY);
   const unsigned lane = threadIdx.x;
   bool any = false, all = true;
-  for (int r = (int)lane; r < kBitCoreY * kBitCoreZ; r += 64) {
-    const int gy = by * kBitCoreY + (r % kBitCoreY), gz = bz * kBitCoreZ + (r / kBitCoreY);
+  for (int r = (int)lane; r < kBitCoreY * a.core_z; r += 64) {
+    const int gy = by * kBitCoreY + (r % kBitCoreY), gz = bz * a.core_z + (r / kBitCoreY);
     if (gy >= a.Y || gz >= a.Z) continue;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -509,171 +574,252 @@ __global__ __launch_bounds__(64) void k_sdfbit_state(const SdfBitArgs a) {
   if (lane == 0u) a.state[b] = w_all ? 2 : (w_any ? 1 : 0);
 }
 
-__global__ __launch_bounds__(256) void k_sdfbit_layers(const SdfBitArgs a) {
-  __shared__ __attribute__((aligned(16))) uint32_t s_reg[kBitReg * kBitReg * 4];  // [rz][ry][4 words]; later the bit-sliced results
-  __shared__ uint32_t s_nb_any, s_all, s_any, s_steps;
-  const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const int b = blockIdx.x;
-  const int bx = b % a.BX, by = (b / a.BX) % a.BY, bz = b / (a.BX * a.BY);
-  const uint8_t own_state = a.state[b];
-  if (own_state == 3) return;
-  // this block's core rows / words inside the volume
-  const int ybase = by * kBitCoreY - kBitHalo, zbase = bz * kBitCoreZ - kBitHalo;
-  uint32_t valid[4], clampfix[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int gw = 2 * bx - 1 + j, x_lo = gw * 32;
-    valid[j] = 0u;
-    clampfix[j] = 0u;
-    if (gw >= 0 && gw < a.WP && x_lo < a.X) {
-      valid[j] = (a.X - x_lo >= 32) ? 0xFFFFFFFFu : ((1u << (a.X - x_lo)) - 1u);
-      clampfix[j] = (gw == 0 ? 1u : 0u) | ((((a.X - 1) >> 5) == gw) ? (1u << ((a.X - 1) & 31)) : 0u);
-    }
-  }
-  if (own_state == 2) {
-    // complete since the previous launch: bring the other buffer up to date, then never come back
-    for (int r = (int)tid; r < kBitCoreY * kBitCoreZ; r += 256) {
-      const int gy = by * kBitCoreY + (r % kBitCoreY), gz = bz * kBitCoreZ + (r / kBitCoreY);
-      if (gy >= a.Y || gz >= a.Z) continue;
-#pragma unroll
-      for (int j = 1; j <= 2; ++j) {
-        const int gw = 2 * bx - 1 + j;
-        if (gw < a.WP) a.r_out[((size_t)gz * a.Y + gy) * (size_t)a.WP + gw] = valid[j];
-      }
-    }
-    if (tid == 0u) a.state[b] = 3;
-    return;
-  }
-  if (tid == 0u) { s_nb_any = 0u; s_all = 1u; s_any = 0u; s_steps = 0u; }
-  __syncthreads();
-  if (tid < 27u) {
-    const int nx = bx + (int)(tid % 3u) - 1, ny = by + (int)((tid / 3u) % 3u) - 1, nz = bz + (int)(tid / 9u) - 1;
-    if (nx >= 0 && ny >= 0 && nz >= 0 && nx < a.BX && ny < a.BY && nz < a.BZ && a.state[((size_t)nz * a.BY + ny) * a.BX + nx] != 0) s_nb_any = 1u;
-  }
-  __syncthreads();
-  if (s_nb_any == 0u) return;  // nothing within reach of the core yet: both buffers hold its (empty) rows
+// lane i <- lane i - 1 / lane i + 1 of the wave (0 beyond the ends): the neighbouring rows along y
+__device__ __forceinline__ uint32_t sdfbit_lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t sdfbit_lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }
 
-  // region rows of this thread: r = tid + 256 i  ->  ry = r & 31, rz = r >> 5
-  uint4 cur[4];
-  bool in_vol[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = (int)tid + 256 * i, ry = r & 31, rz = r >> 5;
-    const int gy = ybase + ry, gz = zbase + rz;
-    in_vol[i] = gy >= 0 && gy < a.Y && gz >= 0 && gz < a.Z;
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
-    if (in_vol[i]) {
-      const uint32_t *row = a.r_in + ((size_t)gz * a.Y + gy) * (size_t)a.WP;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int gw = 2 * bx - 1 + j;
-        if (gw >= 0 && gw < a.WP) w[j] = row[gw];
+// the blocks that can change in the next launch: not complete in both buffers, and a reached voxel in their 27-neighbourhood
+__global__ __launch_bounds__(256) void k_sdfbit_list(const SdfBitArgs a) {
+  const int n_blocks = a.BX * a.BY * a.BZ;
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  bool active = false;
+  if (b < n_blocks) {
+    const int st = a.state[b];
+    active = st == 1 || st == 2;
+    if (st == 0) {
+      const int bx = b % a.BX, by = (b / a.BX) % a.BY, bz = b / (a.BX * a.BY);
+      for (int q = 0; q < 27 && !active; ++q) {
+        const int nx = bx + q % 3 - 1, ny = by + (q / 3) % 3 - 1, nz = bz + q / 9 - 1;
+        if (nx >= 0 && ny >= 0 && nz >= 0 && nx < a.BX && ny < a.BY && nz < a.BZ) active = a.state[((size_t)nz * a.BY + ny) * a.BX + nx] != 0;
       }
     }
-    cur[i] = uint4{w[0], w[1], w[2], w[3]};
-    *reinterpret_cast<uint4 *>(&s_reg[r * 4]) = cur[i];
   }
-  __syncthreads();
+  const unsigned long long m = __ballot(active);
+  if (m == 0ull) return;
+  const unsigned lane = threadIdx.x & 63u;
+  uint32_t base = 0u;
+  if (lane == 0u) base = atomicAdd(a.list_count, (uint32_t)__popcll(m));
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  if (active) a.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint32_t)b;
+}
 
-  // core rows of this thread are i = 1, 2 when ry lies in [8, 24): newly reached bits and their layer, bit-sliced
-  const bool has_core = ((tid & 31u) >= (unsigned)kBitHalo) && ((tid & 31u) < (unsigned)(kBitHalo + kBitCoreY));
-  uint32_t rec_any[2][2] = {{0u, 0u}, {0u, 0u}}, rec_b0[2][2] = {{0u, 0u}, {0u, 0u}}, rec_b1[2][2] = {{0u, 0u}, {0u, 0u}},
-           rec_b2[2][2] = {{0u, 0u}, {0u, 0u}};
-  uint32_t step_mask = 0u;
-  for (int k = 0; k < a.steps; ++k) {
-    uint4 nxt[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      nxt[i] = cur[i];
-      if (!in_vol[i]) continue;
-      const int r = (int)tid + 256 * i, ry = r & 31, rz = r >> 5;
-      const int gy = ybase + ry, gz = zbase + rz;
-      // neighbour rows: clamped to the volume first (the reference's clamp), then to the region (rim rows: never reach the core)
-      const int y0 = min(max(max(gy - 1, 0) - ybase, 0), kBitReg - 1), y1 = min(max(min(gy + 1, a.Y - 1) - ybase, 0), kBitReg - 1);
-      const int z0 = min(max(max(gz - 1, 0) - zbase, 0), kBitReg - 1), z1 = min(max(min(gz + 1, a.Z - 1) - zbase, 0), kBitReg - 1);
-      const uint4 n00 = *reinterpret_cast<const uint4 *>(&s_reg[(z0 * kBitReg + y0) * 4]);
-      const uint4 n10 = *reinterpret_cast<const uint4 *>(&s_reg[(z0 * kBitReg + y1) * 4]);
-      const uint4 n01 = *reinterpret_cast<const uint4 *>(&s_reg[(z1 * kBitReg + y0) * 4]);
-      const uint4 n11 = *reinterpret_cast<const uint4 *>(&s_reg[(z1 * kBitReg + y1) * 4]);
-      const uint32_t u0 = n00.x | n10.x | n01.x | n11.x, u1 = n00.y | n10.y | n01.y | n11.y, u2 = n00.z | n10.z | n01.z | n11.z,
-                     u3 = n00.w | n10.w | n01.w | n11.w;
-      nxt[i].x |= sdfbit_x_neighbours(0u, u0, u1, clampfix[0]) & valid[0];
-      nxt[i].y |= sdfbit_x_neighbours(u0, u1, u2, clampfix[1]) & valid[1];
-      nxt[i].z |= sdfbit_x_neighbours(u1, u2, u3, clampfix[2]) & valid[2];
-      nxt[i].w |= sdfbit_x_neighbours(u2, u3, 0u, clampfix[3]) & valid[3];
-    }
-    if (has_core) {
-#pragma unroll
-      for (int c = 0; c < 2; ++c) {
-        const uint32_t nb0 = nxt[c + 1].y & ~cur[c + 1].y, nb1 = nxt[c + 1].z & ~cur[c + 1].z;
-        rec_any[c][0] |= nb0; rec_any[c][1] |= nb1;
-        if (k & 1) { rec_b0[c][0] |= nb0; rec_b0[c][1] |= nb1; }
-        if (k & 2) { rec_b1[c][0] |= nb0; rec_b1[c][1] |= nb1; }
-        if (k & 4) { rec_b2[c][0] |= nb0; rec_b2[c][1] |= nb1; }
-        if (nb0 | nb1) step_mask |= 1u << k;
-      }
-    }
-    __syncthreads();  // everybody has read layer k
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      cur[i] = nxt[i];
-      *reinterpret_cast<uint4 *>(&s_reg[((int)tid + 256 * i) * 4]) = cur[i];
-    }
+// Eight layers on a 128 x 64 x (4 waves) voxel region of the reached set.  A lane owns four consecutive z-rows (four words
+// each: 32 halo bits, the block's 64 core bits, 32 halo bits) at one y; the rows y - 1 / y + 1 are the neighbouring LANES
+// (two DPP moves per word, no memory), the rows z - 1 / z + 1 the lane's own registers -- only a strip's first and last
+// row cross to the neighbouring wave through LDS (one barrier per layer, ping-pong buffers).  The first version kept the
+// whole region in LDS and read four neighbour rows per row and layer.  The grid is persistent: its blocks take the active
+// regions from the list k_sdfbit_list made (a launch over ALL regions spent 30 us on the inactive ones alone).
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_sdfbit_layers(const SdfBitArgs a) {
+  constexpr int kRegZ = kBitRows * NW, kCoreZ = kRegZ - 2 * kBitHalo;
+  __shared__ uint4 s_x[2][NW][2][64];
+  __shared__ uint32_t s_all, s_any, s_steps, s_entry;
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const int strip = __builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform: scalar branches on the row ranges below
+  const uint32_t n_active = *a.list_count;
+  const bool core_lane = lane >= (unsigned)kBitHalo && lane < (unsigned)(kBitHalo + kBitCoreY);
+  const bool core_strip = strip >= kBitHalo / kBitRows && strip < NW - kBitHalo / kBitRows;
+  for (;;) {
+    __syncthreads();  // the previous region's flags and exchange rows are no longer read
+    if (tid == 0u) { s_entry = atomicAdd(a.list_head, 1u); s_all = 1u; s_any = 0u; s_steps = 0u; }
     __syncthreads();
-  }
-
-  // core rows back to the other bit buffer; the block's state for the next launch
-  bool any = false, all = true;
-  if (has_core) {
+    const uint32_t entry = s_entry;
+    if (entry >= n_active) return;
+    const int b = (int)a.list[entry];
+    const int bx = b % a.BX, by = (b / a.BX) % a.BY, bz = b / (a.BX * a.BY);
+    uint32_t valid[4], clampfix[4];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int i = c + 1;
-      if (!in_vol[i]) continue;
-      const int r = (int)tid + 256 * i, ry = r & 31, rz = r >> 5;
-      uint32_t *row = a.r_out + ((size_t)(zbase + rz) * a.Y + (ybase + ry)) * (size_t)a.WP;
-      const uint32_t w1 = cur[i].y, w2 = cur[i].z;
-      const int gw = 2 * bx;
-      if (gw < a.WP) { row[gw] = w1; any |= w1 != 0u; all &= w1 == valid[1]; }
-      if (gw + 1 < a.WP) { row[gw + 1] = w2; any |= w2 != 0u; all &= w2 == valid[2]; }
+    for (int j = 0; j < 4; ++j) {
+      const int gw = 2 * bx - 1 + j, x_lo = gw * 32;
+      valid[j] = 0u;
+      clampfix[j] = 0u;
+      if (gw >= 0 && gw < a.WP && x_lo < a.X) {
+        valid[j] = (a.X - x_lo >= 32) ? 0xFFFFFFFFu : ((1u << (a.X - x_lo)) - 1u);
+        clampfix[j] = (gw == 0 ? 1u : 0u) | ((((a.X - 1) >> 5) == gw) ? (1u << ((a.X - 1) & 31)) : 0u);
+      }
     }
-  }
-  if (any) s_any = 1u;
-  if (!all) s_all = 0u;
-  if (step_mask) atomicOr(&s_steps, step_mask);
-  __syncthreads();  // also: nobody reads the region any more
-  if (tid == 0u) {
-    a.state[b] = s_all ? 2 : (s_any ? 1 : 0);
-    for (uint32_t m = s_steps; m; m &= m - 1u) a.presence[a.r0 + __ffs((int)m)] = 1;  // layer r0 + k + 1 settled something
-  }
-  if (s_steps == 0u) return;
-
-  // values: the region's LDS now holds {new bits, layer bit 0, 1, 2} x 2 words per core row; lane = voxel
-  if (has_core) {
+    if (a.state[b] == 2) {
+      // complete since the previous launch: bring the other buffer up to date, then never come back
+      for (int r = (int)tid; r < kBitCoreY * kCoreZ; r += 64 * NW) {
+        const int gy = by * kBitCoreY + (r % kBitCoreY), gz = bz * kCoreZ + (r / kBitCoreY);
+        if (gy >= a.Y || gz >= a.Z) continue;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int r = (int)tid + 256 * (c + 1), ry = r & 31, rz = r >> 5;
-      uint32_t *o = &s_reg[(((rz - kBitHalo) * kBitCoreY) + (ry - kBitHalo)) * 8];
-      o[0] = rec_any[c][0]; o[1] = rec_any[c][1]; o[2] = rec_b0[c][0]; o[3] = rec_b0[c][1];
-      o[4] = rec_b1[c][0]; o[5] = rec_b1[c][1]; o[6] = rec_b2[c][0]; o[7] = rec_b2[c][1];
+        for (int j = 1; j <= 2; ++j) {
+          const int gw = 2 * bx - 1 + j;
+          if (gw < a.WP) a.r_out[((size_t)gz * a.Y + gy) * (size_t)a.WP + gw] = valid[j];
+        }
+      }
+      __syncthreads();  // everybody has read the state
+      if (tid == 0u) a.state[b] = 3;
+      continue;
     }
-  }
-  __syncthreads();
-  const int x = bx * 64 + (int)lane;
-  const unsigned j = lane >> 5, bit = lane & 31u;
-  for (int q = 0; q < (kBitCoreY * kBitCoreZ) / 4; ++q) {
-    const int cr = (int)wave * ((kBitCoreY * kBitCoreZ) / 4) + q;  // core row: cy = cr % 16, cz = cr / 16
-    const uint32_t *o = &s_reg[cr * 8];
-    if ((o[0] | o[1]) == 0u) continue;  // wave-uniform
-    if (((o[j] >> bit) & 1u) == 0u) continue;
-    const int gy = by * kBitCoreY + (cr % kBitCoreY), gz = bz * kBitCoreZ + (cr / kBitCoreY);
-    const int k = (int)((o[2 + j] >> bit) & 1u) | ((int)((o[4 + j] >> bit) & 1u) << 1) | ((int)((o[6 + j] >> bit) & 1u) << 2);
-    const int val = a.r0 + k + 2;  // D = r0 + k + 1, value D + 1
-    const uint32_t e = (a.ev[((size_t)gz * a.Y + gy) * (size_t)a.WP + (size_t)(x >> 5)] >> (x & 31)) & 1u;
-    a.sdf[((size_t)gz * a.Y + gy) * (size_t)a.X + (size_t)x] = (int8_t)(e ? -val : val);
+
+    const int gy = by * kBitCoreY - kBitHalo + (int)lane;
+    const int zfirst = bz * kCoreZ - kBitHalo + kBitRows * strip;  // gz of this lane's row 0
+    const bool y_in = gy >= 0 && gy < a.Y;
+    const bool y_border = gy == 0 || gy == a.Y - 1;  // the clamped neighbour along y is the row itself (signed_distance_field.cl:72)
+    const bool blk_y_border = by == 0 || by * kBitCoreY - kBitHalo + 63 >= a.Y - 1;  // does any lane of the block's waves hold such a row?
+    uint32_t cur[kBitRows][4];
+#pragma unroll
+    for (int i = 0; i < kBitRows; ++i) {
+      const int gz = zfirst + i;
+      const bool row_in = y_in && gz >= 0 && gz < a.Z;
+      // the four words are loaded unconditionally (one round trip for all sixteen loads): a row outside the volume reads row 0,
+      // the word before a row's first / after its last belongs to the neighbouring row or buffer of the same allocation
+      const uint32_t *row = a.r_in + (row_in ? ((size_t)gz * a.Y + gy) * (size_t)a.WP : (size_t)0) + (size_t)(2 * bx);
+      const uint32_t w0 = row[-1], w1 = row[0], w2 = row[1], w3 = row[2];
+      cur[i][0] = row_in && bx > 0 ? w0 : 0u;
+      cur[i][1] = row_in ? w1 : 0u;
+      cur[i][2] = row_in ? w2 : 0u;  // WP is even: word 2 bx + 1 exists
+      cur[i][3] = row_in && 2 * bx + 2 < a.WP ? w3 : 0u;
+    }
+    // newly reached bits of the core words (1, 2) and the layer they appeared in, bit-sliced
+    uint32_t rec_any[kBitRows][2], rec_b0[kBitRows][2], rec_b1[kBitRows][2], rec_b2[kBitRows][2];
+#pragma unroll
+    for (int i = 0; i < kBitRows; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) rec_any[i][j] = rec_b0[i][j] = rec_b1[i][j] = rec_b2[i][j] = 0u;
+    uint32_t step_mask = 0u;
+
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k >= a.steps) break;
+      // after k layers a row is exact if it lies at least k rows inside the region: layer k + 1 is computed for the rows
+      // [k + 1, region - 2 - k] from the y-neighbour unions V of the rows [k, region - 1 - k] (the other rows' V is
+      // computed too -- branch-free -- and only ever read by rows that are not needed either)
+      uint32_t v[kBitRows][4];
+      if (blk_y_border) {
+#pragma unroll
+        for (int i = 0; i < kBitRows; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[i][j] = sdfbit_lane_prev(cur[i][j]) | sdfbit_lane_next(cur[i][j]) | (y_border ? cur[i][j] : 0u);
+      } else {
+#pragma unroll
+        for (int i = 0; i < kBitRows; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[i][j] = sdfbit_lane_prev(cur[i][j]) | sdfbit_lane_next(cur[i][j]);
+      }
+      uint4 *xbuf = &s_x[k & 1][0][0][0];
+      xbuf[(strip * 2 + 0) * 64 + lane] = uint4{v[0][0], v[0][1], v[0][2], v[0][3]};
+      xbuf[(strip * 2 + 1) * 64 + lane] = uint4{v[kBitRows - 1][0], v[kBitRows - 1][1], v[kBitRows - 1][2], v[kBitRows - 1][3]};
+      __syncthreads();
+      uint4 below = uint4{0u, 0u, 0u, 0u}, above = uint4{0u, 0u, 0u, 0u};
+      if (strip > 0) below = xbuf[((strip - 1) * 2 + 1) * 64 + lane];
+      if (strip < NW - 1) above = xbuf[((strip + 1) * 2 + 0) * 64 + lane];
+#pragma unroll
+      for (int i = 0; i < kBitRows; ++i) {
+        const int rz = kBitRows * strip + i, gz = zfirst + i;
+        const bool need = rz >= k + 1 && rz <= kRegZ - 2 - k && gz >= 0 && gz < a.Z;  // wave-uniform
+        if (!need) continue;
+        const bool z_border = gz == 0 || gz == a.Z - 1;
+        uint32_t u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t lo = i > 0 ? v[i - 1][j] : (j == 0 ? below.x : j == 1 ? below.y : j == 2 ? below.z : below.w);
+          const uint32_t hi = i < kBitRows - 1 ? v[i + 1][j] : (j == 0 ? above.x : j == 1 ? above.y : j == 2 ? above.z : above.w);
+          u[j] = lo | hi | (z_border ? v[i][j] : 0u);
+        }
+        uint32_t nxt[4];
+        nxt[0] = cur[i][0] | (sdfbit_x_neighbours(0u, u[0], u[1], clampfix[0]) & valid[0]);
+        nxt[1] = cur[i][1] | (sdfbit_x_neighbours(u[0], u[1], u[2], clampfix[1]) & valid[1]);
+        nxt[2] = cur[i][2] | (sdfbit_x_neighbours(u[1], u[2], u[3], clampfix[2]) & valid[2]);
+        nxt[3] = cur[i][3] | (sdfbit_x_neighbours(u[2], u[3], 0u, clampfix[3]) & valid[3]);
+        if (!y_in) nxt[0] = nxt[1] = nxt[2] = nxt[3] = 0u;  // rows beyond the volume do not exist
+        if (core_strip) {
+          const uint32_t nb0 = core_lane ? (nxt[1] & ~cur[i][1]) : 0u, nb1 = core_lane ? (nxt[2] & ~cur[i][2]) : 0u;
+          rec_any[i][0] |= nb0; rec_any[i][1] |= nb1;
+          if (k & 1) { rec_b0[i][0] |= nb0; rec_b0[i][1] |= nb1; }
+          if (k & 2) { rec_b1[i][0] |= nb0; rec_b1[i][1] |= nb1; }
+          if (k & 4) { rec_b2[i][0] |= nb0; rec_b2[i][1] |= nb1; }
+          if (nb0 | nb1) step_mask |= 1u << k;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cur[i][j] = nxt[j];
+      }
+    }
+
+    // core rows back to the other bit buffer; the block's state for the next launch
+    bool any = false, all = true;
+    if (core_strip && core_lane && y_in) {
+#pragma unroll
+      for (int i = 0; i < kBitRows; ++i) {
+        const int gz = zfirst + i;
+        if (gz < 0 || gz >= a.Z) continue;
+        uint32_t *row = a.r_out + ((size_t)gz * a.Y + gy) * (size_t)a.WP;
+        const int gw = 2 * bx;
+        if (gw < a.WP) { row[gw] = cur[i][1]; any |= cur[i][1] != 0u; all &= cur[i][1] == valid[1]; }
+        if (gw + 1 < a.WP) { row[gw + 1] = cur[i][2]; any |= cur[i][2] != 0u; all &= cur[i][2] == valid[2]; }
+      }
+    }
+    if (any) s_any = 1u;
+    if (!all) s_all = 0u;
+    if (step_mask) atomicOr(&s_steps, step_mask);
+    __syncthreads();
+    if (tid == 0u) {
+      a.state[b] = s_all ? 2 : (s_any ? 1 : 0);
+      for (uint32_t m = s_steps; m; m &= m - 1u) a.presence[a.r0 + __ffs((int)m)] = 1;  // layer r0 + k + 1 settled something
+    }
+    if (s_steps == 0u || !core_strip) continue;
+
+    // values: every lane rewrites the 64 bytes of its own rows that gained voxels (the block owns its core rows, so a plain
+    // read-modify-write is race-free): four bits -> four bytes with shifts, the layer bits summed per byte.  The first
+    // version sent each row through the wave (one row per iteration, lane = voxel): 1 to 28 us per region.
+    if (core_lane && y_in) {
+      const uint32_t b1 = 0x01010101u, base = (uint32_t)(a.r0 + 2) * b1;  // D = r0 + k + 1 corner moves from the nearest seed, value D + 1
+#pragma unroll
+      for (int i = 0; i < kBitRows; ++i) {
+        if ((rec_any[i][0] | rec_any[i][1]) == 0u) continue;  // then the row also lies inside the volume
+        const int gz = zfirst + i;
+        const uint32_t *erow = a.ev + ((size_t)gz * a.Y + gy) * (size_t)a.WP + (size_t)(2 * bx);
+        int8_t *out = a.sdf + ((size_t)gz * a.Y + gy) * (size_t)a.X + (size_t)(bx * 64);
+        const uint32_t evw[2] = {erow[0], erow[1]};
+        const bool wide = (a.X & 15) == 0;  // 16-byte accesses; otherwise byte by byte
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {       // 16 voxels
+          const int j = h >> 1, sh = 16 * (h & 1);
+          const uint32_t any16 = (rec_any[i][j] >> sh) & 0xFFFFu;
+          if (any16 == 0u) continue;
+          const uint32_t k0 = (rec_b0[i][j] >> sh) & 0xFFFFu, k1 = (rec_b1[i][j] >> sh) & 0xFFFFu, k2 = (rec_b2[i][j] >> sh) & 0xFFFFu,
+                         e16 = (evw[j] >> sh) & 0xFFFFu;
+          uint32_t val[4], msk[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            auto spread = [&](uint32_t bits16) {  // bits 4q .. 4q+3 -> the low bit of four bytes
+              const uint32_t n = (bits16 >> (4 * q)) & 0xFu;
+              return (n | (n << 7) | (n << 14) | (n << 21)) & b1;
+            };
+            const uint32_t eb = spread(e16);
+            const uint32_t v = base + spread(k0) + 2u * spread(k1) + 4u * spread(k2);  // <= 126 per byte
+            val[q] = (v ^ (eb * 0xFFu)) + eb;                                         // negated where the voxel is an event
+            msk[q] = spread(any16) * 0xFFu;
+          }
+          if (wide) {
+            uint4 *p = reinterpret_cast<uint4 *>(out + 16 * h);
+            const uint4 old = *p;
+            *p = uint4{(old.x & ~msk[0]) | (val[0] & msk[0]), (old.y & ~msk[1]) | (val[1] & msk[1]), (old.z & ~msk[2]) | (val[2] & msk[2]),
+                       (old.w & ~msk[3]) | (val[3] & msk[3])};
+          } else {
+            for (int c = 0; c < 16; ++c)
+              if ((any16 >> c) & 1u) out[16 * h + c] = (int8_t)(val[c >> 2] >> (8 * (c & 3)));
+          }
+        }
+      }
+    }
   }
 }
 
+void sdfbit_block_grid(int X, int Y, int Z, int waves, int32_t *BX, int32_t *BY, int32_t *BZ, int32_t *core_z) {
+  *core_z = kBitRows * waves - 2 * kBitHalo;
+  *BX = (X + 63) / 64;
+  *BY = (Y + kBitCoreY - 1) / kBitCoreY;
+  *BZ = (Z + *core_z - 1) / *core_z;
+}
+
 hipError_t launch_sdfbit_events(const SdfArgs &a, uint32_t *ev, int32_t WP, hipStream_t s) {
+  if (!a.tf.uses_gradient && !a.cls_in && (a.X % 8) == 0) {
+    hipLaunchKernelGGL(k_sdfbit_events8, sdfbit_row_grid((uint32_t)WP * 4u, (size_t)a.Y * (size_t)a.Z), dim3(256), 0, s, a, (uint8_t *)ev, WP);
+    return hipGetLastError();
+  }
   const dim3 grid(((unsigned)a.X + 255u) / 256u, (unsigned)a.Y, (unsigned)a.Z);
   if (a.tf.uses_gradient)
     hipLaunchKernelGGL(k_sdfbit_events<true>, grid, dim3(256), 0, s, a, ev, WP);
@@ -683,10 +829,15 @@ hipError_t launch_sdfbit_events(const SdfArgs &a, uint32_t *ev, int32_t WP, hipS
 }
 
 hipError_t launch_sdfbit_seed_init(const SdfBitArgs &a, int32_t max_iterations, hipStream_t s) {
-  hipLaunchKernelGGL(k_sdfbit_seed, dim3(((unsigned)a.WP + 255u) / 256u, (unsigned)a.Y, (unsigned)a.Z), dim3(256), 0, s, a.ev, a.r_out, a.X, a.Y, a.Z,
-                     a.WP, a.presence);
-  hipLaunchKernelGGL(k_sdfbit_init, dim3(((unsigned)a.X + 255u) / 256u, (unsigned)a.Y, (unsigned)a.Z), dim3(256), 0, s, a.ev, (const uint32_t *)a.r_out,
-                     a.sdf, a.X, a.Y, a.Z, a.WP, max_iterations);
+  const size_t n_rows = (size_t)a.Y * (size_t)a.Z;
+  hipLaunchKernelGGL(k_sdfbit_seed, sdfbit_row_grid((uint32_t)a.WP, n_rows), dim3(256), 0, s, a.ev, a.r_out, a.X, a.Y, a.Z, a.WP, a.presence);
+  if ((a.X % 16) == 0 && max_iterations >= 1) {
+    hipLaunchKernelGGL(k_sdfbit_init16, sdfbit_row_grid((uint32_t)(a.X / 16), n_rows), dim3(256), 0, s, a.ev, (const uint32_t *)a.r_out, a.sdf, a.X, a.Y,
+                       a.Z, a.WP, max_iterations);
+  } else {
+    hipLaunchKernelGGL(k_sdfbit_init, dim3(((unsigned)a.X + 255u) / 256u, (unsigned)a.Y, (unsigned)a.Z), dim3(256), 0, s, a.ev, (const uint32_t *)a.r_out,
+                       a.sdf, a.X, a.Y, a.Z, a.WP, max_iterations);
+  }
   return hipGetLastError();
 }
 
@@ -695,8 +846,15 @@ hipError_t launch_sdfbit_state(const SdfBitArgs &a, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_sdfbit_layers(const SdfBitArgs &a, hipStream_t s) {
-  hipLaunchKernelGGL(k_sdfbit_layers, dim3((unsigned)(a.BX * a.BY * a.BZ)), dim3(256), 0, s, a);
+// one launch = the list of the regions that can change + up to eight layers on them (persistent grid of `grid_blocks`)
+hipError_t launch_sdfbit_layers(const SdfBitArgs &a, int waves, unsigned grid_blocks, hipStream_t s) {
+  const unsigned n_blocks = (unsigned)(a.BX * a.BY * a.BZ);
+  hipLaunchKernelGGL(k_sdfbit_list, dim3((n_blocks + 255u) / 256u), dim3(256), 0, s, a);
+  const unsigned grid = std::min(n_blocks, grid_blocks);
+  if (waves == 16)
+    hipLaunchKernelGGL(k_sdfbit_layers<16>, dim3(grid), dim3(64 * 16), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_sdfbit_layers<8>, dim3(grid), dim3(64 * 8), 0, s, a);
   return hipGetLastError();
 }
 

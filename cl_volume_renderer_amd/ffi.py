@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclwhip.so")
+# CLWH_LIBRARY: another build of the same library (tools/ experiments: timing probes, tuning variants)
+LIB_PATH = os.environ.get("CLWH_LIBRARY") or os.path.join(_HERE, "libclwhip.so")
 
 OK = 0
 ELEM_S8, ELEM_S16, ELEM_S32, ELEM_U8, ELEM_U16, ELEM_U32, ELEM_F32 = range(7)
