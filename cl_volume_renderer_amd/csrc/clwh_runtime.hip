@@ -1017,11 +1017,12 @@ static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settl
   const int total = b.max_iterations - 2;
   const int n_launches = total > 0 ? (total + 7) / 8 : 0;
   // scratch: event bits, two reached-set buffers, the list of active blocks, per-launch {count, head}, block states
-  const size_t scratch_words = 3 * words + n_blocks + 2 * (size_t)(n_launches + 1);
+  const size_t scratch_words = 3 * words + n_blocks + 2 * (size_t)(n_launches + 1) + ((n_blocks + 2 * (size_t)(n_launches + 1)) & 1u) + 2 * n_blocks;  // ... + 8-byte bounding boxes
   int rc = grow(ctx, (void **)&ctx->sdf_bits, &ctx->sdf_bits_bytes, scratch_words * sizeof(uint32_t) + n_blocks);
   if (rc != CLWH_OK) return rc;
   uint32_t *ev = ctx->sdf_bits, *reached[2] = {ctx->sdf_bits + words, ctx->sdf_bits + 2 * words};
   uint32_t *list = ctx->sdf_bits + 3 * words, *queue = list + n_blocks;
+  a.bbox = reinterpret_cast<unsigned long long *>(ctx->sdf_bits + scratch_words - 2 * n_blocks);  // 8-byte aligned: 3 words is even (WP is), the pad word above
   a.sdf = b.ping;
   a.ev = ev;
   a.list = list;
@@ -1046,6 +1047,13 @@ static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settl
   }
   HIP_TRY(hipMemcpyAsync(settled.data(), ctx->sdf_counters, kSlots * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (std::getenv("CLWH_DEBUG_SDFBIT")) {  // regions each launch worked on
+    std::vector<uint32_t> q(2 * (size_t)(n_launches + 1));
+    HIP_TRY(hipMemcpy(q.data(), queue, q.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "sdfbit: %zu regions of 64 x 48 x %d voxels, active per launch:", n_blocks, a.core_z);
+    for (int l = 0; l < n_launches; ++l) std::fprintf(stderr, " %u", q[2 * l]);
+    std::fprintf(stderr, "\n");
+  }
   return CLWH_OK;
 }
 

@@ -468,11 +468,20 @@ __global__ __launch_bounds__(256) void k_sdfbit_events8(const SdfArgs a, uint8_t
   if (x0 < a.X) {  // X is a multiple of 8: all eight voxels exist
     const uint4 q = *reinterpret_cast<const uint4 *>(a.volume + row * (size_t)a.X + (size_t)x0);
     const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+    int value[8];
 #pragma unroll
-    for (int h = 0; h < 8; ++h) {
-      uint32_t color = 0u;
-      const int value = (int)(int16_t)(w[h >> 1] >> (16 * (h & 1)));
-      bits |= tf_eval(a.tf, value, 0, color) ? (1u << h) : 0u;
+    for (int h = 0; h < 8; ++h) value[h] = (int)(int16_t)(w[h >> 1] >> (16 * (h & 1)));
+    // tf_eval for the eight voxels at once, the rule (one scalar load of its bounds) in the outer loop: the first matching
+    // rule decides, a terminal rule that does not match decides "no event" (render_device.hpp: tf_eval)
+    uint32_t undecided = 0xFFu;
+    for (int k = 0; k < a.tf.n && undecided; ++k) {
+      const int lo = a.tf.rules[k].v_lo, hi = a.tf.rules[k].v_hi;
+      uint32_t m = 0u;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) m |= (value[h] >= lo && value[h] <= hi) ? (1u << h) : 0u;
+      bits |= m & undecided;
+      undecided &= ~m;
+      if (a.tf.rules[k].flags & TF_TERMINAL) undecided = 0u;
     }
   }
   ev_bytes[row * (size_t)WP * 4u + unit] = (uint8_t)bits;
@@ -551,14 +560,25 @@ __global__ __launch_bounds__(256) void k_sdfbit_init16(const uint32_t *__restric
 constexpr int kBitCoreY = 48, kBitHalo = 8, kBitRows = 4;  // a wave = 64 rows along y (48 core + 2 x 8 halo) x 4 rows along z
 // a block = NW waves (8 or 16) = NW strips of 4 z-rows: region z = 4 NW, core z = 4 NW - 16 (SdfBitArgs::core_z)
 
-// block state: 0 = no reached voxel in the core, 1 = some, 2 = all (just now: the other bit buffer is not complete yet), 3 = all, both buffers
+// block state: 0 = no reached voxel in the core, 1 = some, 2 = all (just now: the other bit buffer is not complete yet), 3 = all, both buffers.
+// bbox: the box (relative to the core, inclusive) around the core's reached voxels: x0 | x1 << 8 | y0 << 16 | y1 << 24 | z0 << 32 | z1 << 40
+__device__ __forceinline__ unsigned long long sdfbit_pack_bbox(uint32_t orx0, uint32_t orx1, int y0, int y1, int z0, int z1) {
+  const unsigned long long orx = (unsigned long long)orx0 | ((unsigned long long)orx1 << 32);
+  const int x0 = __ffsll((long long)orx) - 1, x1 = 63 - __clzll((long long)orx);
+  return (unsigned long long)(unsigned)x0 | ((unsigned long long)(unsigned)x1 << 8) | ((unsigned long long)(unsigned)y0 << 16) |
+         ((unsigned long long)(unsigned)y1 << 24) | ((unsigned long long)(unsigned)z0 << 32) | ((unsigned long long)(unsigned)z1 << 40);
+}
+
 __global__ __launch_bounds__(64) void k_sdfbit_state(const SdfBitArgs a) {
   const int b = blockIdx.x;
   const int bx = b % a.BX, by = (b / a.BX) % a.BY, bz = b / (a.BX * a.BY);
   const unsigned lane = threadIdx.x;
   bool any = false, all = true;
+  uint32_t orx[2] = {0u, 0u};
+  int y0 = 255, y1 = -1, z0 = 255, z1 = -1;
   for (int r = (int)lane; r < kBitCoreY * a.core_z; r += 64) {
-    const int gy = by * kBitCoreY + (r % kBitCoreY), gz = bz * a.core_z + (r / kBitCoreY);
+    const int cy = r % kBitCoreY, cz = r / kBitCoreY;
+    const int gy = by * kBitCoreY + cy, gz = bz * a.core_z + cz;
     if (gy >= a.Y || gz >= a.Z) continue;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -568,64 +588,179 @@ __global__ __launch_bounds__(64) void k_sdfbit_state(const SdfBitArgs a) {
       const uint32_t wv = a.r_in[((size_t)gz * a.Y + gy) * (size_t)a.WP + gw];
       any |= wv != 0u;
       all &= wv == valid;
+      orx[j] |= wv;
+      if (wv) { y0 = min(y0, cy); y1 = max(y1, cy); z0 = min(z0, cz); z1 = max(z1, cz); }
     }
   }
+  for (int off = 32; off > 0; off >>= 1) {
+    orx[0] |= (uint32_t)__shfl_xor((int)orx[0], off); orx[1] |= (uint32_t)__shfl_xor((int)orx[1], off);
+    y0 = min(y0, __shfl_xor(y0, off)); y1 = max(y1, __shfl_xor(y1, off));
+    z0 = min(z0, __shfl_xor(z0, off)); z1 = max(z1, __shfl_xor(z1, off));
+  }
   const bool w_any = __ballot(any) != 0ull, w_all = __ballot(!all) == 0ull;
-  if (lane == 0u) a.state[b] = w_all ? 2 : (w_any ? 1 : 0);
+  if (lane == 0u) {
+    a.state[b] = w_all ? 2 : (w_any ? 1 : 0);
+    if (w_any) a.bbox[b] = sdfbit_pack_bbox(orx[0], orx[1], y0, y1, z0, z1);
+  }
 }
 
 // lane i <- lane i - 1 / lane i + 1 of the wave (0 beyond the ends): the neighbouring rows along y
 __device__ __forceinline__ uint32_t sdfbit_lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t sdfbit_lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }
 
-// the blocks that can change in the next launch: not complete in both buffers, and a reached voxel in their 27-neighbourhood
-__global__ __launch_bounds__(256) void k_sdfbit_list(const SdfBitArgs a) {
+// the blocks that can change in the next launch: not complete in both buffers, and a reached voxel within 8 voxels (Chebyshev; a
+// corner move changes every coordinate by at most one) of their core -- for an empty block: in a neighbour's bounding box.
+// (The first version woke an empty block as soon as a neighbour held ANY reached voxel, up to 16 launches before the front
+// arrived: two thirds of the regions a launch worked on could not change.)
+__device__ __forceinline__ void sdfbit_build_list(const SdfBitArgs &a, uint32_t *count, int first, int stride) {
   const int n_blocks = a.BX * a.BY * a.BZ;
-  const int b = blockIdx.x * 256 + threadIdx.x;
-  bool active = false;
-  if (b < n_blocks) {
-    const int st = a.state[b];
-    active = st == 1 || st == 2;
-    if (st == 0) {
-      const int bx = b % a.BX, by = (b / a.BX) % a.BY, bz = b / (a.BX * a.BY);
-      for (int q = 0; q < 27 && !active; ++q) {
-        const int nx = bx + q % 3 - 1, ny = by + (q / 3) % 3 - 1, nz = bz + q / 9 - 1;
-        if (nx >= 0 && ny >= 0 && nz >= 0 && nx < a.BX && ny < a.BY && nz < a.BZ) active = a.state[((size_t)nz * a.BY + ny) * a.BX + nx] != 0;
+  const int rounds = (n_blocks + stride - 1) / stride;  // every wave runs the same number of rounds (ballots below)
+  for (int r = 0; r < rounds; ++r) {
+    const int b = first + r * stride;
+    bool active = false, complete = false;
+    if (b < n_blocks) {
+      const int st = a.state[b];
+      active = st == 1 || st == 2;
+      complete = st == 2;
+      if (st == 0) {
+        const int bx = b % a.BX, by = (b / a.BX) % a.BY, bz = b / (a.BX * a.BY);
+        const int cx0 = bx * 64, cx1 = min(cx0 + 63, a.X - 1), cy0 = by * kBitCoreY, cy1 = min(cy0 + kBitCoreY - 1, a.Y - 1), cz0 = bz * a.core_z,
+                  cz1 = min(cz0 + a.core_z - 1, a.Z - 1);
+        for (int q = 0; q < 27 && !active; ++q) {
+          const int nx = bx + q % 3 - 1, ny = by + (q / 3) % 3 - 1, nz = bz + q / 9 - 1;
+          if (nx < 0 || ny < 0 || nz < 0 || nx >= a.BX || ny >= a.BY || nz >= a.BZ) continue;
+          const size_t nb = ((size_t)nz * a.BY + ny) * a.BX + nx;
+          if (a.state[nb] == 0) continue;
+          const unsigned long long bb = a.bbox[nb];
+          const int rx0 = nx * 64 + (int)(bb & 0xFF), rx1 = nx * 64 + (int)((bb >> 8) & 0xFF), ry0 = ny * kBitCoreY + (int)((bb >> 16) & 0xFF),
+                    ry1 = ny * kBitCoreY + (int)((bb >> 24) & 0xFF), rz0 = nz * a.core_z + (int)((bb >> 32) & 0xFF), rz1 = nz * a.core_z + (int)((bb >> 40) & 0xFF);
+          const int gx = max(max(rx0 - cx1, cx0 - rx1), 0), gy = max(max(ry0 - cy1, cy0 - ry1), 0), gz = max(max(rz0 - cz1, cz0 - rz1), 0);
+          active = gx <= kBitHalo && gy <= kBitHalo && gz <= kBitHalo;
+        }
       }
     }
+    const unsigned long long m = __ballot(active);
+    if (m == 0ull) continue;
+    uint32_t base = 0u;
+    if ((threadIdx.x & 63u) == 0u) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (active)
+      a.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint32_t)b | (complete ? 0x80000000u : 0u);
   }
-  const unsigned long long m = __ballot(active);
-  if (m == 0ull) return;
-  const unsigned lane = threadIdx.x & 63u;
-  uint32_t base = 0u;
-  if (lane == 0u) base = atomicAdd(a.list_count, (uint32_t)__popcll(m));
-  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-  if (active) a.list[base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (uint32_t)b;
+}
+
+// (one launch per list: letting the last block of the layers kernel make the next list was tried -- a single block needs 30 us
+// for the dependent state / bounding-box reads that 2816 threads spread over the chip finish in 5)
+__global__ __launch_bounds__(256) void k_sdfbit_list(const SdfBitArgs a) {
+  sdfbit_build_list(a, a.list_count, (int)(blockIdx.x * 256u + threadIdx.x), (int)(gridDim.x * 256u));
 }
 
 // Eight layers on a 128 x 64 x (4 waves) voxel region of the reached set.  A lane owns four consecutive z-rows (four words
 // each: 32 halo bits, the block's 64 core bits, 32 halo bits) at one y; the rows y - 1 / y + 1 are the neighbouring LANES
 // (two DPP moves per word, no memory), the rows z - 1 / z + 1 the lane's own registers -- only a strip's first and last
 // row cross to the neighbouring wave through LDS (one barrier per layer, ping-pong buffers).  The first version kept the
-// whole region in LDS and read four neighbour rows per row and layer.  The grid is persistent: its blocks take the active
-// regions from the list k_sdfbit_list made (a launch over ALL regions spent 30 us on the inactive ones alone).
+// whole region in LDS and read four neighbour rows per row and layer.  INTERIOR: the region touches no face of the volume
+// (no clamped neighbour, no missing row or bit): about half the instructions.
+struct SdfBitLane {
+  uint32_t cur[kBitRows][4];
+  // newly reached bits of the core words (1, 2) and the layer they appeared in, bit-sliced
+  uint32_t rec_any[kBitRows][2], rec_b0[kBitRows][2], rec_b1[kBitRows][2], rec_b2[kBitRows][2];
+  uint32_t step_mask;
+};
+
+template <int NW, bool INTERIOR>
+__device__ __forceinline__ void sdfbit_steps(SdfBitLane &L, uint4 (*s_x)[NW][2][64], int steps, int strip, unsigned lane, bool core_lane, bool core_strip,
+                                             const uint32_t (&valid)[4], const uint32_t (&clampfix)[4], bool y_in, bool y_border, int zfirst, int Z) {
+  constexpr int kRegZ = kBitRows * NW;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k >= steps) break;
+    // after k layers a row is exact if it lies at least k rows inside the region: layer k + 1 is computed for the rows
+    // [k + 1, region - 2 - k] from the y-neighbour unions V of the rows [k, region - 1 - k] (the other rows' V is
+    // computed too -- branch-free -- and only ever read by rows that are not needed either)
+    uint32_t v[kBitRows][4];
+#pragma unroll
+    for (int i = 0; i < kBitRows; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[i][j] = sdfbit_lane_prev(L.cur[i][j]) | sdfbit_lane_next(L.cur[i][j]);
+        if (!INTERIOR) v[i][j] |= y_border ? L.cur[i][j] : 0u;
+      }
+    uint4 *xbuf = &s_x[k & 1][0][0][0];
+    xbuf[(strip * 2 + 0) * 64 + lane] = uint4{v[0][0], v[0][1], v[0][2], v[0][3]};
+    xbuf[(strip * 2 + 1) * 64 + lane] = uint4{v[kBitRows - 1][0], v[kBitRows - 1][1], v[kBitRows - 1][2], v[kBitRows - 1][3]};
+    __syncthreads();
+    uint4 below = uint4{0u, 0u, 0u, 0u}, above = uint4{0u, 0u, 0u, 0u};
+    if (strip > 0) below = xbuf[((strip - 1) * 2 + 1) * 64 + lane];
+    if (strip < NW - 1) above = xbuf[((strip + 1) * 2 + 0) * 64 + lane];
+#pragma unroll
+    for (int i = 0; i < kBitRows; ++i) {
+      const int rz = kBitRows * strip + i, gz = zfirst + i;
+      bool need = rz >= k + 1 && rz <= kRegZ - 2 - k;  // wave-uniform
+      if (!INTERIOR) need = need && gz >= 0 && gz < Z;
+      if (!need) continue;
+      const bool z_border = !INTERIOR && (gz == 0 || gz == Z - 1);
+      uint32_t u[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t lo = i > 0 ? v[i - 1][j] : (j == 0 ? below.x : j == 1 ? below.y : j == 2 ? below.z : below.w);
+        const uint32_t hi = i < kBitRows - 1 ? v[i + 1][j] : (j == 0 ? above.x : j == 1 ? above.y : j == 2 ? above.z : above.w);
+        u[j] = lo | hi;
+        if (!INTERIOR) u[j] |= z_border ? v[i][j] : 0u;
+      }
+      uint32_t nxt[4];
+      if (INTERIOR) {
+        nxt[0] = L.cur[i][0] | sdfbit_x_neighbours(0u, u[0], u[1], 0u);
+        nxt[1] = L.cur[i][1] | sdfbit_x_neighbours(u[0], u[1], u[2], 0u);
+        nxt[2] = L.cur[i][2] | sdfbit_x_neighbours(u[1], u[2], u[3], 0u);
+        nxt[3] = L.cur[i][3] | sdfbit_x_neighbours(u[2], u[3], 0u, 0u);
+      } else {
+        nxt[0] = L.cur[i][0] | (sdfbit_x_neighbours(0u, u[0], u[1], clampfix[0]) & valid[0]);
+        nxt[1] = L.cur[i][1] | (sdfbit_x_neighbours(u[0], u[1], u[2], clampfix[1]) & valid[1]);
+        nxt[2] = L.cur[i][2] | (sdfbit_x_neighbours(u[1], u[2], u[3], clampfix[2]) & valid[2]);
+        nxt[3] = L.cur[i][3] | (sdfbit_x_neighbours(u[2], u[3], 0u, clampfix[3]) & valid[3]);
+        if (!y_in) nxt[0] = nxt[1] = nxt[2] = nxt[3] = 0u;  // rows beyond the volume do not exist
+      }
+      if (core_strip) {
+        const uint32_t nb0 = core_lane ? (nxt[1] & ~L.cur[i][1]) : 0u, nb1 = core_lane ? (nxt[2] & ~L.cur[i][2]) : 0u;
+        L.rec_any[i][0] |= nb0; L.rec_any[i][1] |= nb1;
+        if (k & 1) { L.rec_b0[i][0] |= nb0; L.rec_b0[i][1] |= nb1; }
+        if (k & 2) { L.rec_b1[i][0] |= nb0; L.rec_b1[i][1] |= nb1; }
+        if (k & 4) { L.rec_b2[i][0] |= nb0; L.rec_b2[i][1] |= nb1; }
+        if (nb0 | nb1) L.step_mask |= 1u << k;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) L.cur[i][j] = nxt[j];
+    }
+  }
+}
+
+// The grid is persistent: its blocks take the active regions from the list k_sdfbit_list made (a launch over ALL regions
+// spent 30 us on the inactive ones alone); a block's first region is list[blockIdx.x], the following ones come from a queue.
 template <int NW>
-__global__ __launch_bounds__(64 * NW) void k_sdfbit_layers(const SdfBitArgs a) {
+__global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a) {
   constexpr int kRegZ = kBitRows * NW, kCoreZ = kRegZ - 2 * kBitHalo;
   __shared__ uint4 s_x[2][NW][2][64];
-  __shared__ uint32_t s_all, s_any, s_steps, s_entry;
+  __shared__ uint32_t s_all, s_any, s_steps, s_entry, s_orx[2];
+  __shared__ int s_box[4];  // min y, max y, min z, max z of the core's reached voxels
   const unsigned tid = threadIdx.x, lane = tid & 63u;
   const int strip = __builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform: scalar branches on the row ranges below
   const uint32_t n_active = *a.list_count;
   const bool core_lane = lane >= (unsigned)kBitHalo && lane < (unsigned)(kBitHalo + kBitCoreY);
   const bool core_strip = strip >= kBitHalo / kBitRows && strip < NW - kBitHalo / kBitRows;
-  for (;;) {
+  for (uint32_t round = 0u;; ++round) {
     __syncthreads();  // the previous region's flags and exchange rows are no longer read
-    if (tid == 0u) { s_entry = atomicAdd(a.list_head, 1u); s_all = 1u; s_any = 0u; s_steps = 0u; }
+    if (tid == 0u) {
+      // dynamic: regions differ in cost (complete ones only copy); a static round-robin over the list measured 1.84 ms against 1.60
+      s_entry = round == 0u ? blockIdx.x : gridDim.x + atomicAdd(a.list_head, 1u);
+      s_all = 1u; s_any = 0u; s_steps = 0u; s_orx[0] = 0u; s_orx[1] = 0u;
+      s_box[0] = 255; s_box[1] = -1; s_box[2] = 255; s_box[3] = -1;
+    }
     __syncthreads();
     const uint32_t entry = s_entry;
     if (entry >= n_active) return;
-    const int b = (int)a.list[entry];
+    const uint32_t item = a.list[entry];  // block | complete-since-the-previous-launch << 31
+    const int b = (int)(item & 0x7FFFFFFFu);
     const int bx = b % a.BX, by = (b / a.BX) % a.BY, bz = b / (a.BX * a.BY);
     uint32_t valid[4], clampfix[4];
 #pragma unroll
@@ -638,7 +773,7 @@ __global__ __launch_bounds__(64 * NW) void k_sdfbit_layers(const SdfBitArgs a) {
         clampfix[j] = (gw == 0 ? 1u : 0u) | ((((a.X - 1) >> 5) == gw) ? (1u << ((a.X - 1) & 31)) : 0u);
       }
     }
-    if (a.state[b] == 2) {
+    if (item >> 31) {
       // complete since the previous launch: bring the other buffer up to date, then never come back
       for (int r = (int)tid; r < kBitCoreY * kCoreZ; r += 64 * NW) {
         const int gy = by * kBitCoreY + (r % kBitCoreY), gz = bz * kCoreZ + (r / kBitCoreY);
@@ -649,7 +784,6 @@ __global__ __launch_bounds__(64 * NW) void k_sdfbit_layers(const SdfBitArgs a) {
           if (gw < a.WP) a.r_out[((size_t)gz * a.Y + gy) * (size_t)a.WP + gw] = valid[j];
         }
       }
-      __syncthreads();  // everybody has read the state
       if (tid == 0u) a.state[b] = 3;
       continue;
     }
@@ -658,8 +792,10 @@ __global__ __launch_bounds__(64 * NW) void k_sdfbit_layers(const SdfBitArgs a) {
     const int zfirst = bz * kCoreZ - kBitHalo + kBitRows * strip;  // gz of this lane's row 0
     const bool y_in = gy >= 0 && gy < a.Y;
     const bool y_border = gy == 0 || gy == a.Y - 1;  // the clamped neighbour along y is the row itself (signed_distance_field.cl:72)
-    const bool blk_y_border = by == 0 || by * kBitCoreY - kBitHalo + 63 >= a.Y - 1;  // does any lane of the block's waves hold such a row?
-    uint32_t cur[kBitRows][4];
+    // no face of the volume inside the region or next to it: every word, row and neighbour exists, nothing is clamped
+    const bool interior = bx >= 1 && (2 * bx + 3) * 32 < a.X && by * kBitCoreY - kBitHalo >= 1 && by * kBitCoreY - kBitHalo + 63 <= a.Y - 2 &&
+                          bz * kCoreZ - kBitHalo >= 1 && bz * kCoreZ - kBitHalo + kRegZ - 1 <= a.Z - 2;
+    SdfBitLane L;
 #pragma unroll
     for (int i = 0; i < kBitRows; ++i) {
       const int gz = zfirst + i;
@@ -668,77 +804,20 @@ __global__ __launch_bounds__(64 * NW) void k_sdfbit_layers(const SdfBitArgs a) {
       // the word before a row's first / after its last belongs to the neighbouring row or buffer of the same allocation
       const uint32_t *row = a.r_in + (row_in ? ((size_t)gz * a.Y + gy) * (size_t)a.WP : (size_t)0) + (size_t)(2 * bx);
       const uint32_t w0 = row[-1], w1 = row[0], w2 = row[1], w3 = row[2];
-      cur[i][0] = row_in && bx > 0 ? w0 : 0u;
-      cur[i][1] = row_in ? w1 : 0u;
-      cur[i][2] = row_in ? w2 : 0u;  // WP is even: word 2 bx + 1 exists
-      cur[i][3] = row_in && 2 * bx + 2 < a.WP ? w3 : 0u;
+      L.cur[i][0] = row_in && bx > 0 ? w0 : 0u;
+      L.cur[i][1] = row_in ? w1 : 0u;
+      L.cur[i][2] = row_in ? w2 : 0u;  // WP is even: word 2 bx + 1 exists
+      L.cur[i][3] = row_in && 2 * bx + 2 < a.WP ? w3 : 0u;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) L.rec_any[i][j] = L.rec_b0[i][j] = L.rec_b1[i][j] = L.rec_b2[i][j] = 0u;
     }
-    // newly reached bits of the core words (1, 2) and the layer they appeared in, bit-sliced
-    uint32_t rec_any[kBitRows][2], rec_b0[kBitRows][2], rec_b1[kBitRows][2], rec_b2[kBitRows][2];
-#pragma unroll
-    for (int i = 0; i < kBitRows; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) rec_any[i][j] = rec_b0[i][j] = rec_b1[i][j] = rec_b2[i][j] = 0u;
-    uint32_t step_mask = 0u;
+    L.step_mask = 0u;
+    if (interior)
+      sdfbit_steps<NW, true>(L, s_x, a.steps, strip, lane, core_lane, core_strip, valid, clampfix, y_in, y_border, zfirst, a.Z);
+    else
+      sdfbit_steps<NW, false>(L, s_x, a.steps, strip, lane, core_lane, core_strip, valid, clampfix, y_in, y_border, zfirst, a.Z);
 
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (k >= a.steps) break;
-      // after k layers a row is exact if it lies at least k rows inside the region: layer k + 1 is computed for the rows
-      // [k + 1, region - 2 - k] from the y-neighbour unions V of the rows [k, region - 1 - k] (the other rows' V is
-      // computed too -- branch-free -- and only ever read by rows that are not needed either)
-      uint32_t v[kBitRows][4];
-      if (blk_y_border) {
-#pragma unroll
-        for (int i = 0; i < kBitRows; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[i][j] = sdfbit_lane_prev(cur[i][j]) | sdfbit_lane_next(cur[i][j]) | (y_border ? cur[i][j] : 0u);
-      } else {
-#pragma unroll
-        for (int i = 0; i < kBitRows; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[i][j] = sdfbit_lane_prev(cur[i][j]) | sdfbit_lane_next(cur[i][j]);
-      }
-      uint4 *xbuf = &s_x[k & 1][0][0][0];
-      xbuf[(strip * 2 + 0) * 64 + lane] = uint4{v[0][0], v[0][1], v[0][2], v[0][3]};
-      xbuf[(strip * 2 + 1) * 64 + lane] = uint4{v[kBitRows - 1][0], v[kBitRows - 1][1], v[kBitRows - 1][2], v[kBitRows - 1][3]};
-      __syncthreads();
-      uint4 below = uint4{0u, 0u, 0u, 0u}, above = uint4{0u, 0u, 0u, 0u};
-      if (strip > 0) below = xbuf[((strip - 1) * 2 + 1) * 64 + lane];
-      if (strip < NW - 1) above = xbuf[((strip + 1) * 2 + 0) * 64 + lane];
-#pragma unroll
-      for (int i = 0; i < kBitRows; ++i) {
-        const int rz = kBitRows * strip + i, gz = zfirst + i;
-        const bool need = rz >= k + 1 && rz <= kRegZ - 2 - k && gz >= 0 && gz < a.Z;  // wave-uniform
-        if (!need) continue;
-        const bool z_border = gz == 0 || gz == a.Z - 1;
-        uint32_t u[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t lo = i > 0 ? v[i - 1][j] : (j == 0 ? below.x : j == 1 ? below.y : j == 2 ? below.z : below.w);
-          const uint32_t hi = i < kBitRows - 1 ? v[i + 1][j] : (j == 0 ? above.x : j == 1 ? above.y : j == 2 ? above.z : above.w);
-          u[j] = lo | hi | (z_border ? v[i][j] : 0u);
-        }
-        uint32_t nxt[4];
-        nxt[0] = cur[i][0] | (sdfbit_x_neighbours(0u, u[0], u[1], clampfix[0]) & valid[0]);
-        nxt[1] = cur[i][1] | (sdfbit_x_neighbours(u[0], u[1], u[2], clampfix[1]) & valid[1]);
-        nxt[2] = cur[i][2] | (sdfbit_x_neighbours(u[1], u[2], u[3], clampfix[2]) & valid[2]);
-        nxt[3] = cur[i][3] | (sdfbit_x_neighbours(u[2], u[3], 0u, clampfix[3]) & valid[3]);
-        if (!y_in) nxt[0] = nxt[1] = nxt[2] = nxt[3] = 0u;  // rows beyond the volume do not exist
-        if (core_strip) {
-          const uint32_t nb0 = core_lane ? (nxt[1] & ~cur[i][1]) : 0u, nb1 = core_lane ? (nxt[2] & ~cur[i][2]) : 0u;
-          rec_any[i][0] |= nb0; rec_any[i][1] |= nb1;
-          if (k & 1) { rec_b0[i][0] |= nb0; rec_b0[i][1] |= nb1; }
-          if (k & 2) { rec_b1[i][0] |= nb0; rec_b1[i][1] |= nb1; }
-          if (k & 4) { rec_b2[i][0] |= nb0; rec_b2[i][1] |= nb1; }
-          if (nb0 | nb1) step_mask |= 1u << k;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cur[i][j] = nxt[j];
-      }
-    }
-
-    // core rows back to the other bit buffer; the block's state for the next launch
+    // core rows back to the other bit buffer; the block's state and bounding box for the next launch
     bool any = false, all = true;
     if (core_strip && core_lane && y_in) {
 #pragma unroll
@@ -747,28 +826,36 @@ __global__ __launch_bounds__(64 * NW) void k_sdfbit_layers(const SdfBitArgs a) {
         if (gz < 0 || gz >= a.Z) continue;
         uint32_t *row = a.r_out + ((size_t)gz * a.Y + gy) * (size_t)a.WP;
         const int gw = 2 * bx;
-        if (gw < a.WP) { row[gw] = cur[i][1]; any |= cur[i][1] != 0u; all &= cur[i][1] == valid[1]; }
-        if (gw + 1 < a.WP) { row[gw + 1] = cur[i][2]; any |= cur[i][2] != 0u; all &= cur[i][2] == valid[2]; }
+        if (gw < a.WP) { row[gw] = L.cur[i][1]; any |= L.cur[i][1] != 0u; all &= L.cur[i][1] == valid[1]; }
+        if (gw + 1 < a.WP) { row[gw + 1] = L.cur[i][2]; any |= L.cur[i][2] != 0u; all &= L.cur[i][2] == valid[2]; }
+        if (L.cur[i][1] | L.cur[i][2]) {  // words beyond the volume are zero (valid mask)
+          const int cz = kBitRows * strip + i - kBitHalo;
+          atomicMin(&s_box[2], cz);
+          atomicMax(&s_box[3], cz);
+        }
       }
     }
-    if (any) s_any = 1u;
-    if (!all) s_all = 0u;
-    if (step_mask) atomicOr(&s_steps, step_mask);
-    __syncthreads();
-    if (tid == 0u) {
-      a.state[b] = s_all ? 2 : (s_any ? 1 : 0);
-      for (uint32_t m = s_steps; m; m &= m - 1u) a.presence[a.r0 + __ffs((int)m)] = 1;  // layer r0 + k + 1 settled something
+    if (any) {
+      s_any = 1u;
+      uint32_t o1 = 0u, o2 = 0u;
+#pragma unroll
+      for (int i = 0; i < kBitRows; ++i) { o1 |= L.cur[i][1]; o2 |= L.cur[i][2]; }  // rows outside the volume hold zeros
+      if (o1) atomicOr(&s_orx[0], o1);
+      if (o2) atomicOr(&s_orx[1], o2);
+      atomicMin(&s_box[0], (int)lane - kBitHalo);
+      atomicMax(&s_box[1], (int)lane - kBitHalo);
     }
-    if (s_steps == 0u || !core_strip) continue;
+    if (!all) s_all = 0u;
+    if (L.step_mask) atomicOr(&s_steps, L.step_mask);
 
     // values: every lane rewrites the 64 bytes of its own rows that gained voxels (the block owns its core rows, so a plain
     // read-modify-write is race-free): four bits -> four bytes with shifts, the layer bits summed per byte.  The first
     // version sent each row through the wave (one row per iteration, lane = voxel): 1 to 28 us per region.
-    if (core_lane && y_in) {
+    if (core_strip && core_lane && y_in) {
       const uint32_t b1 = 0x01010101u, base = (uint32_t)(a.r0 + 2) * b1;  // D = r0 + k + 1 corner moves from the nearest seed, value D + 1
 #pragma unroll
       for (int i = 0; i < kBitRows; ++i) {
-        if ((rec_any[i][0] | rec_any[i][1]) == 0u) continue;  // then the row also lies inside the volume
+        if ((L.rec_any[i][0] | L.rec_any[i][1]) == 0u) continue;  // then the row also lies inside the volume
         const int gz = zfirst + i;
         const uint32_t *erow = a.ev + ((size_t)gz * a.Y + gy) * (size_t)a.WP + (size_t)(2 * bx);
         int8_t *out = a.sdf + ((size_t)gz * a.Y + gy) * (size_t)a.X + (size_t)(bx * 64);
@@ -777,9 +864,9 @@ __global__ __launch_bounds__(64 * NW) void k_sdfbit_layers(const SdfBitArgs a) {
 #pragma unroll
         for (int h = 0; h < 4; ++h) {       // 16 voxels
           const int j = h >> 1, sh = 16 * (h & 1);
-          const uint32_t any16 = (rec_any[i][j] >> sh) & 0xFFFFu;
+          const uint32_t any16 = (L.rec_any[i][j] >> sh) & 0xFFFFu;
           if (any16 == 0u) continue;
-          const uint32_t k0 = (rec_b0[i][j] >> sh) & 0xFFFFu, k1 = (rec_b1[i][j] >> sh) & 0xFFFFu, k2 = (rec_b2[i][j] >> sh) & 0xFFFFu,
+          const uint32_t k0 = (L.rec_b0[i][j] >> sh) & 0xFFFFu, k1 = (L.rec_b1[i][j] >> sh) & 0xFFFFu, k2 = (L.rec_b2[i][j] >> sh) & 0xFFFFu,
                          e16 = (evw[j] >> sh) & 0xFFFFu;
           uint32_t val[4], msk[4];
 #pragma unroll
@@ -804,6 +891,12 @@ __global__ __launch_bounds__(64 * NW) void k_sdfbit_layers(const SdfBitArgs a) {
           }
         }
       }
+    }
+    __syncthreads();
+    if (tid == 0u) {
+      a.state[b] = s_all ? 2 : (s_any ? 1 : 0);
+      if (s_any) a.bbox[b] = sdfbit_pack_bbox(s_orx[0], s_orx[1], s_box[0], s_box[1], s_box[2], s_box[3]);
+      for (uint32_t m = s_steps; m; m &= m - 1u) a.presence[a.r0 + __ffs((int)m)] = 1;  // layer r0 + k + 1 settled something
     }
   }
 }
@@ -849,7 +942,7 @@ hipError_t launch_sdfbit_state(const SdfBitArgs &a, hipStream_t s) {
 // one launch = the list of the regions that can change + up to eight layers on them (persistent grid of `grid_blocks`)
 hipError_t launch_sdfbit_layers(const SdfBitArgs &a, int waves, unsigned grid_blocks, hipStream_t s) {
   const unsigned n_blocks = (unsigned)(a.BX * a.BY * a.BZ);
-  hipLaunchKernelGGL(k_sdfbit_list, dim3((n_blocks + 255u) / 256u), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_sdfbit_list, dim3(std::min((n_blocks + 255u) / 256u, 1024u)), dim3(256), 0, s, a);
   const unsigned grid = std::min(n_blocks, grid_blocks);
   if (waves == 16)
     hipLaunchKernelGGL(k_sdfbit_layers<16>, dim3(grid), dim3(64 * 16), 0, s, a);
