@@ -188,6 +188,9 @@ struct SdfBitArgs {
   uint32_t *list;          // blocks that can change in this launch (k_sdfbit_list)
   uint32_t *list_count;    // their number; list_head: the persistent grid's queue position
   uint32_t *list_head;
+#ifdef CLVR_SDFBIT_TIMING
+  unsigned long long *timing;  // tools/ builds only: per-phase sums of wall_clock64 ticks over all regions
+#endif
 };
 void sdfbit_block_grid(int X, int Y, int Z, int waves, int32_t *BX, int32_t *BY, int32_t *BZ, int32_t *core_z);  // blocks of 64 x 48 x (4 waves - 16) voxels
 hipError_t launch_sdfbit_events(const SdfArgs &a, uint32_t *ev, int32_t WP, hipStream_t s);

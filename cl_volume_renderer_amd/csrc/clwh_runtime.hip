@@ -1035,6 +1035,12 @@ static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settl
   HIP_TRY(launch_sdfbit_seed_init(a, b.max_iterations, ctx->stream));
   a.r_in = reached[0];
   HIP_TRY(launch_sdfbit_state(a, ctx->stream));
+#ifdef CLVR_SDFBIT_TIMING
+  static unsigned long long *d_timing = nullptr;
+  if (!d_timing) HIP_TRY(hipMalloc((void **)&d_timing, 8 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemsetAsync(d_timing, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  a.timing = d_timing;
+#endif
   int t = 0;
   for (int r0 = 0; r0 < total; r0 += 8, ++t) {
     a.r0 = r0;
@@ -1047,6 +1053,15 @@ static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settl
   }
   HIP_TRY(hipMemcpyAsync(settled.data(), ctx->sdf_counters, kSlots * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+#ifdef CLVR_SDFBIT_TIMING
+  {
+    unsigned long long tm[8];
+    HIP_TRY(hipMemcpy(tm, d_timing, sizeof tm, hipMemcpyDeviceToHost));
+    const double n = tm[0] ? (double)tm[0] : 1.0;
+    std::fprintf(stderr, "sdfbit timing: %llu regions (%llu interior); per region, us: fetch %.2f load %.2f steps %.2f store+values %.2f tail %.2f\n", tm[0], tm[6],
+                 tm[1] / n / 100.0, tm[2] / n / 100.0, tm[3] / n / 100.0, tm[4] / n / 100.0, tm[5] / n / 100.0);
+  }
+#endif
   if (std::getenv("CLWH_DEBUG_SDFBIT")) {  // regions each launch worked on
     std::vector<uint32_t> q(2 * (size_t)(n_launches + 1));
     HIP_TRY(hipMemcpy(q.data(), queue, q.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -757,6 +757,10 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
       s_box[0] = 255; s_box[1] = -1; s_box[2] = 255; s_box[3] = -1;
     }
     __syncthreads();
+#ifdef CLVR_SDFBIT_TIMING
+    const bool probe = tid == 64u * 2u + 8u;
+    const unsigned long long tq0 = wall_clock64();
+#endif
     const uint32_t entry = s_entry;
     if (entry >= n_active) return;
     const uint32_t item = a.list[entry];  // block | complete-since-the-previous-launch << 31
@@ -795,6 +799,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
     // no face of the volume inside the region or next to it: every word, row and neighbour exists, nothing is clamped
     const bool interior = bx >= 1 && (2 * bx + 3) * 32 < a.X && by * kBitCoreY - kBitHalo >= 1 && by * kBitCoreY - kBitHalo + 63 <= a.Y - 2 &&
                           bz * kCoreZ - kBitHalo >= 1 && bz * kCoreZ - kBitHalo + kRegZ - 1 <= a.Z - 2;
+#ifdef CLVR_SDFBIT_TIMING
+    const unsigned long long tq1 = wall_clock64();
+#endif
     SdfBitLane L;
 #pragma unroll
     for (int i = 0; i < kBitRows; ++i) {
@@ -812,11 +819,18 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
       for (int j = 0; j < 2; ++j) L.rec_any[i][j] = L.rec_b0[i][j] = L.rec_b1[i][j] = L.rec_b2[i][j] = 0u;
     }
     L.step_mask = 0u;
+#ifdef CLVR_SDFBIT_TIMING
+    if (probe) __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long tq2 = wall_clock64();
+#endif
     if (interior)
       sdfbit_steps<NW, true>(L, s_x, a.steps, strip, lane, core_lane, core_strip, valid, clampfix, y_in, y_border, zfirst, a.Z);
     else
       sdfbit_steps<NW, false>(L, s_x, a.steps, strip, lane, core_lane, core_strip, valid, clampfix, y_in, y_border, zfirst, a.Z);
 
+#ifdef CLVR_SDFBIT_TIMING
+    const unsigned long long tq3 = wall_clock64();
+#endif
     // core rows back to the other bit buffer; the block's state and bounding box for the next launch
     bool any = false, all = true;
     if (core_strip && core_lane && y_in) {
@@ -853,14 +867,21 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
     // version sent each row through the wave (one row per iteration, lane = voxel): 1 to 28 us per region.
     if (core_strip && core_lane && y_in) {
       const uint32_t b1 = 0x01010101u, base = (uint32_t)(a.r0 + 2) * b1;  // D = r0 + k + 1 corner moves from the nearest seed, value D + 1
+      const bool wide = (a.X & 15) == 0;  // 16-byte accesses; otherwise byte by byte
 #pragma unroll
       for (int i = 0; i < kBitRows; ++i) {
         if ((L.rec_any[i][0] | L.rec_any[i][1]) == 0u) continue;  // then the row also lies inside the volume
         const int gz = zfirst + i;
         const uint32_t *erow = a.ev + ((size_t)gz * a.Y + gy) * (size_t)a.WP + (size_t)(2 * bx);
         int8_t *out = a.sdf + ((size_t)gz * a.Y + gy) * (size_t)a.X + (size_t)(bx * 64);
+        // all of the row's loads first (one round trip per row; a branch per 16-voxel group cost sixteen)
         const uint32_t evw[2] = {erow[0], erow[1]};
-        const bool wide = (a.X & 15) == 0;  // 16-byte accesses; otherwise byte by byte
+        uint4 old[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          old[h] = uint4{0u, 0u, 0u, 0u};
+          if (wide && bx * 64 + 16 * h < a.X) old[h] = *reinterpret_cast<const uint4 *>(out + 16 * h);
+        }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {       // 16 voxels
           const int j = h >> 1, sh = 16 * (h & 1);
@@ -881,10 +902,8 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
             msk[q] = spread(any16) * 0xFFu;
           }
           if (wide) {
-            uint4 *p = reinterpret_cast<uint4 *>(out + 16 * h);
-            const uint4 old = *p;
-            *p = uint4{(old.x & ~msk[0]) | (val[0] & msk[0]), (old.y & ~msk[1]) | (val[1] & msk[1]), (old.z & ~msk[2]) | (val[2] & msk[2]),
-                       (old.w & ~msk[3]) | (val[3] & msk[3])};
+            *reinterpret_cast<uint4 *>(out + 16 * h) = uint4{(old[h].x & ~msk[0]) | (val[0] & msk[0]), (old[h].y & ~msk[1]) | (val[1] & msk[1]),
+                                                             (old[h].z & ~msk[2]) | (val[2] & msk[2]), (old[h].w & ~msk[3]) | (val[3] & msk[3])};
           } else {
             for (int c = 0; c < 16; ++c)
               if ((any16 >> c) & 1u) out[16 * h + c] = (int8_t)(val[c >> 2] >> (8 * (c & 3)));
@@ -892,7 +911,17 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
         }
       }
     }
+#ifdef CLVR_SDFBIT_TIMING
+    if (probe) __builtin_amdgcn_s_waitcnt(0);
+    const unsigned long long tq4 = wall_clock64();
+#endif
     __syncthreads();
+#ifdef CLVR_SDFBIT_TIMING
+    if (probe) {
+      atomicAdd(&a.timing[0], 1ull); atomicAdd(&a.timing[1], tq1 - tq0); atomicAdd(&a.timing[2], tq2 - tq1); atomicAdd(&a.timing[3], tq3 - tq2);
+      atomicAdd(&a.timing[4], tq4 - tq3); atomicAdd(&a.timing[5], wall_clock64() - tq4); atomicAdd(&a.timing[6], interior ? 1ull : 0ull);
+    }
+#endif
     if (tid == 0u) {
       a.state[b] = s_all ? 2 : (s_any ? 1 : 0);
       if (s_any) a.bbox[b] = sdfbit_pack_bbox(s_orx[0], s_orx[1], s_box[0], s_box[1], s_box[2], s_box[3]);
