@@ -109,3 +109,30 @@ def gpu_ctx_long_big_cells():
         del os.environ["CLWH_TUNE_MACRO_SHIFT"]
     yield ctx
     ctx.destroy()
+
+
+def _ctx_with_env(env):
+    from cl_volume_renderer_amd import ffi
+
+    os.environ.update(env)
+    try:
+        return ffi.Context(0)
+    finally:
+        for k in env:
+            del os.environ[k]
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_sdf_front():
+    """a context whose clwh_sdf_build runs the byte front (one launch per layer) instead of the bit-parallel build"""
+    ctx = _ctx_with_env({"CLWH_TUNE_SDF": "front"})
+    yield ctx
+    ctx.destroy()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_sdf_waves16():
+    """the bit-parallel SDF build with 16-wave blocks (regions of 64 x 48 x 48 voxels instead of 64 x 48 x 16)"""
+    ctx = _ctx_with_env({"CLWH_TUNE_SDFBIT_WAVES": "16"})
+    yield ctx
+    ctx.destroy()

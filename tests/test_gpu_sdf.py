@@ -124,3 +124,46 @@ def test_sdf_at_512_equals_the_committed_oracle_checksum(gpu_ctx, golden_dir, tf
     assert int(sdf.astype(np.int64).sum()) == want["sum"]
     assert hashlib.sha256(sdf.tobytes()).hexdigest() == want["sha256"]
     v.release(); s.release()
+
+
+def _blobs(dims, seed):
+    """random smooth blobs: fronts in every direction, seeds in all four parity classes, surfaces that meet the volume's faces"""
+    rng = np.random.default_rng(seed)
+    Z, Y, X = dims[2], dims[1], dims[0]
+    z, y, x = np.mgrid[0:Z, 0:Y, 0:X].astype(np.float32)
+    vol = np.full((Z, Y, X), -900.0, np.float32)
+    for _ in range(5):
+        c = rng.uniform(0, 1, 3) * np.array([X, Y, Z])
+        r = rng.uniform(0.08, 0.3) * max(dims)
+        vol = np.maximum(vol, 1000.0 - 60.0 * (np.sqrt((x - c[0]) ** 2 + (y - c[1]) ** 2 + (z - c[2]) ** 2) - r))
+    return np.ascontiguousarray(np.clip(vol, -1000, 1100).astype(np.int16))
+
+
+@pytest.mark.parametrize("variant", ["bits", "bits16", "front"])
+@pytest.mark.parametrize("dims", [(200, 170, 150), (65, 49, 17), (2, 40, 40), (130, 3, 7), (31, 97, 129)])
+def test_every_build_variant_on_awkward_shapes(gpu_ctx, gpu_ctx_sdf_waves16, gpu_ctx_sdf_front, orc, variant, dims):
+    """The bit-parallel build works on regions of 64 x 48 x 16 (or 48) voxels with 8-voxel halos, rows of 32-bit words and a
+    clamped neighbourhood at the faces: sizes that are no multiple of any of these, one-voxel-thick volumes, and surfaces that
+    run into the faces -- every value and the reference's launch count against the oracle, for all three build paths."""
+    ctx = {"bits": gpu_ctx, "bits16": gpu_ctx_sdf_waves16, "front": gpu_ctx_sdf_front}[variant]
+    vol = _blobs(dims, seed=sum(dims))
+    tf = scene.tf_default_source()
+    want, n_want, _ = orc.sdf_build(vol, orc.parse_tf(tf))
+    v, s = _upload(ctx, vol)
+    n = ctx.sdf_build(v, tf, s)
+    got = s.pull()
+    assert np.array_equal(got, want)
+    assert n == n_want
+    assert (np.abs(want.astype(np.int32)) > 1).any() or min(dims) < 4  # something was propagated
+    v.release(); s.release()
+
+
+def test_rebuild_after_a_transfer_function_change(gpu_ctx, orc):
+    """the build's scratch (bit sets, block states, lists) is reused across builds: a second build with another table must not see the first"""
+    vol = scene.phantom(96)
+    v, s = _upload(gpu_ctx, vol)
+    for src in (scene.tf_default_source(), scene.tf_gradient_source(), scene.tf_default_source()):
+        want, n_want, _ = orc.sdf_build(vol, orc.parse_tf(src))
+        n = gpu_ctx.sdf_build(v, src, s)
+        assert np.array_equal(s.pull(), want) and n == n_want
+    v.release(); s.release()
