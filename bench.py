@@ -103,7 +103,16 @@ def spawn_ranks(n):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    raise SystemExit(subprocess.call(cmd, env=env))
+    # rank 0 prints the one JSON line; whatever else the ranks' libraries write to stdout (gloo's connection banner in a
+    # rehearsal) goes to stderr so that stdout stays that single line
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:
+        if line.lstrip().startswith("{"):
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        elif line.strip():
+            sys.stderr.write(line)
+    raise SystemExit(child.wait())
 
 
 # ---------------------------------------------------------------------------------------------------------------
