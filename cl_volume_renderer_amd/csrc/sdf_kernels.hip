@@ -892,14 +892,14 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
           uint32_t val[4], msk[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            auto spread = [&](uint32_t bits16) {  // bits 4q .. 4q+3 -> the low bit of four bytes
-              const uint32_t n = (bits16 >> (4 * q)) & 0xFu;
-              return (n | (n << 7) | (n << 14) | (n << 21)) & b1;
+            auto spread = [&](uint32_t bits16) {  // bits 4q .. 4q+3 -> the low bit of four bytes (one 24-bit multiply: no carries between the copies)
+              return __umul24((bits16 >> (4 * q)) & 0xFu, 0x204081u) & b1;
             };
+            auto bytes_ff = [](uint32_t ones) { return (ones << 8) - ones; };  // 0 / 1 per byte -> 0x00 / 0xFF (= ones * 255 mod 2^32)
             const uint32_t eb = spread(e16);
             const uint32_t v = base + spread(k0) + 2u * spread(k1) + 4u * spread(k2);  // <= 126 per byte
-            val[q] = (v ^ (eb * 0xFFu)) + eb;                                         // negated where the voxel is an event
-            msk[q] = spread(any16) * 0xFFu;
+            val[q] = (v ^ bytes_ff(eb)) + eb;                                         // negated where the voxel is an event
+            msk[q] = bytes_ff(spread(any16));
           }
           if (wide) {
             *reinterpret_cast<uint4 *>(out + 16 * h) = uint4{(old[h].x & ~msk[0]) | (val[0] & msk[0]), (old[h].y & ~msk[1]) | (val[1] & msk[1]),
