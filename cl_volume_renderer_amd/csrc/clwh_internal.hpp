@@ -252,7 +252,7 @@ struct clwh_ctx {
   int32_t tune_unit_group = 1, tune_unit_affinity = 0, tune_unit_queues = 8;
   int32_t tune_cert_min_step = -1;  // CLWH_TUNE_CERT: 0 = exit certificates off; -1 = by volume size (16 at 512^3, 32 at 1024^3, 48 at 2048^3:
                                     // the best of the sweeps in profiles/r02_sweep_k_bounce_lds_state.txt)
-  uint32_t tune_bounce_max_blocks = 2048;
+  uint32_t tune_bounce_max_blocks = 2048;  // CLWH_TUNE_BLOCKS
   bool primary_valid = false;
   uint32_t primary_n_hits = 0;
   bool primary_n_hits_known = false;  // false: the count of this camera's hits is only on the device so far

@@ -995,6 +995,9 @@ hipError_t launch_bounce(const RenderArgs &a_in, hipStream_t s) {
   // persistent grid: enough waves to fill the chip (256 CUs x 32 waves), never more than the work
   const uint64_t waves_needed = (total + 63u) / 64u;
   constexpr unsigned wpb = (unsigned)kBounceThreads / 64u;  // waves per block; bounce_max_blocks counts 256-thread blocks
+  // (two frame jobs in flight on two streams share the chip: a rank's share of a multi-GPU job -- a few million items -- runs 9 % (4 ranks)
+  // to 18 % (8 ranks) faster when each launch takes half the grid, CLWH_TUNE_BLOCKS=1024, which bench.py sets for such runs; alone on the
+  // GPU the same launch is 20-30 % slower on half the grid, so the default stays the full chip: profiles/r02_emulate_rank_grid_sweep.txt)
   const unsigned blocks = (unsigned)std::min<uint64_t>((waves_needed + wpb - 1u) / wpb, ((uint64_t)a.bounce_max_blocks * 4u + wpb - 1u) / wpb);
   const dim3 grid(blocks), block(kBounceThreads);
   // Scheduling thresholds (0 = automatic).  A launch with only a few units per wave (one or a few passes) is
