@@ -1016,19 +1016,22 @@ static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settl
   // a voxel D corner moves from the nearest seed settles to D + 1 while D + 1 < max_iterations: max_iterations - 2 layers
   const int total = b.max_iterations - 2;
   const int n_launches = total > 0 ? (total + 7) / 8 : 0;
-  // scratch: event bits, two reached-set buffers, the list of active blocks, per-launch {count, head}, block states
-  const size_t scratch_words = 3 * words + n_blocks + 2 * (size_t)(n_launches + 1) + ((n_blocks + 2 * (size_t)(n_launches + 1)) & 1u) + 2 * n_blocks;  // ... + 8-byte bounding boxes
+  // scratch: event bits (x-fastest rows), two reached-set buffers (tiled by region, padded to whole regions), the list of active
+  // blocks, per-launch {count, head}, the regions' bounding boxes and states
+  const size_t tiled = n_blocks * (size_t)(2 * 48 * a.core_z);
+  const size_t small = n_blocks + 2 * (size_t)(n_launches + 1);
+  const size_t scratch_words = words + 2 * tiled + small + (small & 1u) + 2 * n_blocks;
   int rc = grow(ctx, (void **)&ctx->sdf_bits, &ctx->sdf_bits_bytes, scratch_words * sizeof(uint32_t) + n_blocks);
   if (rc != CLWH_OK) return rc;
-  uint32_t *ev = ctx->sdf_bits, *reached[2] = {ctx->sdf_bits + words, ctx->sdf_bits + 2 * words};
-  uint32_t *list = ctx->sdf_bits + 3 * words, *queue = list + n_blocks;
-  a.bbox = reinterpret_cast<unsigned long long *>(ctx->sdf_bits + scratch_words - 2 * n_blocks);  // 8-byte aligned: 3 words is even (WP is), the pad word above
+  uint32_t *ev = ctx->sdf_bits, *reached[2] = {ctx->sdf_bits + words, ctx->sdf_bits + words + tiled};
+  uint32_t *list = ctx->sdf_bits + words + 2 * tiled, *queue = list + n_blocks;
+  a.bbox = reinterpret_cast<unsigned long long *>(ctx->sdf_bits + scratch_words - 2 * n_blocks);  // 8-byte aligned: words and tiled are even, the pad word above
   a.sdf = b.ping;
   a.ev = ev;
   a.list = list;
   a.state = reinterpret_cast<uint8_t *>(ctx->sdf_bits + scratch_words);
   a.presence = ctx->sdf_counters;
-  HIP_TRY(hipMemsetAsync(reached[1], 0, words * sizeof(uint32_t), ctx->stream));  // rows nobody ever writes must read as empty in both buffers
+  HIP_TRY(hipMemsetAsync(reached[0], 0, 2 * tiled * sizeof(uint32_t), ctx->stream));  // rows nobody ever writes (beyond the volume, never reached) read as empty in both buffers
   HIP_TRY(hipMemsetAsync(queue, 0, 2 * (size_t)(n_launches + 1) * sizeof(uint32_t), ctx->stream));
   HIP_TRY(launch_sdfbit_events(b, ev, a.WP, ctx->stream));
   a.r_out = reached[0];

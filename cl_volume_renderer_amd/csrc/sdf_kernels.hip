@@ -493,9 +493,22 @@ __device__ __forceinline__ uint32_t sdfbit_x_neighbours(uint32_t prev, uint32_t 
   return ((cur << 1) | (prev >> 31)) | ((cur >> 1) | (next << 31)) | (cur & clampfix);
 }
 
+// The reached-set buffers are TILED by region: tile (bx, by, bz) = the region's core, 48 * core_z rows of two words, row (cy, cz) at
+// ((cz * 48 + cy) * 2): the rows a wave of k_sdfbit_layers loads / stores (64 lanes = 64 consecutive y) are contiguous 8-byte pairs.
+// (In the x-fastest layout of the event bits the same rows lie 64 bytes apart at 512^3: every lane its own cache line, and the
+// address unit, not the layers, set the pace of a region.)  Tiles are padded to full size; rows beyond the volume stay zero.
+struct SdfBitTiles {
+  int32_t BX, BY, core_z;
+  __device__ __forceinline__ size_t tile_words() const { return (size_t)2 * 48u * (size_t)core_z; }
+  __device__ __forceinline__ size_t word(int w, int y, int z) const {
+    const int bx = w >> 1, by = y / 48, cy = y - by * 48, bz = z / core_z, cz = z - bz * core_z;
+    return (((size_t)bz * BY + by) * BX + bx) * tile_words() + (size_t)((cz * 48 + cy) * 2 + (w & 1));
+  }
+};
+
 // non-homogeneous voxels (create_base_image: some clamped corner neighbour's event flag differs) = the seeds R_0
 __global__ __launch_bounds__(256) void k_sdfbit_seed(const uint32_t *__restrict__ ev, uint32_t *__restrict__ r0, int32_t X, int32_t Y,
-                                                      int32_t Z, int32_t WP, int32_t *presence) {
+                                                      int32_t Z, int32_t WP, int32_t *presence, SdfBitTiles tiles) {
   size_t rowi;
   uint32_t unit;
   if (!sdfbit_row_unit((uint32_t)WP, (size_t)Y * (size_t)Z, rowi, unit)) return;
@@ -519,32 +532,33 @@ __global__ __launch_bounds__(256) void k_sdfbit_seed(const uint32_t *__restrict_
     differs |= (left ^ own) | (right ^ own);
   }
   differs &= valid;
-  r0[rowi * (size_t)WP + w] = differs;
+  r0[tiles.word(w, y, z)] = differs;
   if (differs) presence[0] = 1;  // non-zero marker, plain store (see k_sdf_base_front)
 }
 
 // base image from the two bit sets: +-1 at a seed, +-max_iterations elsewhere
 __global__ __launch_bounds__(256) void k_sdfbit_init(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ r0, int8_t *__restrict__ sdf,
-                                                      int32_t X, int32_t Y, int32_t Z, int32_t WP, int32_t max_iterations) {
+                                                      int32_t X, int32_t Y, int32_t Z, int32_t WP, int32_t max_iterations, SdfBitTiles tiles) {
   const int x = blockIdx.x * 256 + threadIdx.x;
   const int y = blockIdx.y, z = blockIdx.z;
   if (x >= X) return;
   const size_t roww = ((size_t)z * Y + y) * (size_t)WP + (size_t)(x >> 5);
-  const uint32_t e = (ev[roww] >> (x & 31)) & 1u, s = (r0[roww] >> (x & 31)) & 1u;
+  const uint32_t e = (ev[roww] >> (x & 31)) & 1u, s = (r0[tiles.word(x >> 5, y, z)] >> (x & 31)) & 1u;
   const int val = s ? 1 : max_iterations;
   sdf[((size_t)z * Y + y) * (size_t)X + (size_t)x] = (int8_t)(e ? -val : val);
 }
 
 // the same, sixteen voxels (one 16-byte store) per lane: rows of a multiple of 16 voxels, max_iterations >= 1
 __global__ __launch_bounds__(256) void k_sdfbit_init16(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ r0, int8_t *__restrict__ sdf,
-                                                        int32_t X, int32_t Y, int32_t Z, int32_t WP, int32_t max_iterations) {
+                                                        int32_t X, int32_t Y, int32_t Z, int32_t WP, int32_t max_iterations, SdfBitTiles tiles) {
   size_t row;
   uint32_t unit;
   if (!sdfbit_row_unit((uint32_t)(X / 16), (size_t)Y * (size_t)Z, row, unit)) return;
   const uint32_t b1 = 0x01010101u, mb = (uint32_t)max_iterations * b1, dm = (uint32_t)(max_iterations - 1);
   const int x0 = (int)unit * 16;
   const size_t wi = row * (size_t)WP + (size_t)(x0 >> 5);
-  const uint32_t e16 = (ev[wi] >> (x0 & 31)) & 0xFFFFu, s16 = (r0[wi] >> (x0 & 31)) & 0xFFFFu;
+  const int z = (int)(row / (size_t)Y), y = (int)(row - (size_t)z * (size_t)Y);
+  const uint32_t e16 = (ev[wi] >> (x0 & 31)) & 0xFFFFu, s16 = (r0[tiles.word(x0 >> 5, y, z)] >> (x0 & 31)) & 0xFFFFu;
   uint32_t out[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -585,7 +599,7 @@ __global__ __launch_bounds__(64) void k_sdfbit_state(const SdfBitArgs a) {
       const int gw = 2 * bx + j, x_lo = gw * 32;
       if (gw >= a.WP || x_lo >= a.X) continue;
       const uint32_t valid = (a.X - x_lo >= 32) ? 0xFFFFFFFFu : ((1u << (a.X - x_lo)) - 1u);
-      const uint32_t wv = a.r_in[((size_t)gz * a.Y + gy) * (size_t)a.WP + gw];
+      const uint32_t wv = a.r_in[(size_t)b * (size_t)(2 * kBitCoreY * a.core_z) + (size_t)(r * 2 + j)];
       any |= wv != 0u;
       all &= wv == valid;
       orx[j] |= wv;
@@ -785,7 +799,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
 #pragma unroll
         for (int j = 1; j <= 2; ++j) {
           const int gw = 2 * bx - 1 + j;
-          if (gw < a.WP) a.r_out[((size_t)gz * a.Y + gy) * (size_t)a.WP + gw] = valid[j];
+          if (gw < a.WP) a.r_out[(size_t)b * (size_t)(2 * kBitCoreY * kCoreZ) + (size_t)(r * 2 + j - 1)] = valid[j];
         }
       }
       if (tid == 0u) a.state[b] = 3;
@@ -803,18 +817,28 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
     const unsigned long long tq1 = wall_clock64();
 #endif
     SdfBitLane L;
+    // this lane's y: its tile row (by - 1 / by / by + 1) and row inside the tile
+    const int lane_by = by + ((int)lane < kBitHalo ? -1 : ((int)lane >= kBitHalo + kBitCoreY ? 1 : 0));
+    const int lane_cy = (int)lane < kBitHalo ? kBitCoreY - kBitHalo + (int)lane : ((int)lane >= kBitHalo + kBitCoreY ? (int)lane - kBitHalo - kBitCoreY : (int)lane - kBitHalo);
+    const bool y_tile = lane_by >= 0 && lane_by < a.BY;
+    constexpr size_t kTileWords = (size_t)2 * kBitCoreY * kCoreZ;
 #pragma unroll
     for (int i = 0; i < kBitRows; ++i) {
-      const int gz = zfirst + i;
-      const bool row_in = y_in && gz >= 0 && gz < a.Z;
-      // the four words are loaded unconditionally (one round trip for all sixteen loads): a row outside the volume reads row 0,
-      // the word before a row's first / after its last belongs to the neighbouring row or buffer of the same allocation
-      const uint32_t *row = a.r_in + (row_in ? ((size_t)gz * a.Y + gy) * (size_t)a.WP : (size_t)0) + (size_t)(2 * bx);
-      const uint32_t w0 = row[-1], w1 = row[0], w2 = row[1], w3 = row[2];
-      L.cur[i][0] = row_in && bx > 0 ? w0 : 0u;
-      L.cur[i][1] = row_in ? w1 : 0u;
-      L.cur[i][2] = row_in ? w2 : 0u;  // WP is even: word 2 bx + 1 exists
-      L.cur[i][3] = row_in && 2 * bx + 2 < a.WP ? w3 : 0u;
+      const int rz = kBitRows * strip + i;
+      const int row_bz = bz + (rz < kBitHalo ? -1 : (rz >= kBitHalo + kCoreZ ? 1 : 0));
+      const int row_cz = rz < kBitHalo ? kCoreZ - kBitHalo + rz : (rz >= kBitHalo + kCoreZ ? rz - kBitHalo - kCoreZ : rz - kBitHalo);
+      const bool row_in = y_tile && row_bz >= 0 && row_bz < a.BZ;  // the tile exists; its rows beyond the volume hold zeros
+      // all loads are issued unconditionally (one round trip): a missing tile reads tile 0 and is masked afterwards
+      const size_t t_mid = row_in ? (((size_t)row_bz * a.BY + lane_by) * a.BX + bx) : (size_t)0;
+      const size_t in_tile = (size_t)((row_cz * kBitCoreY + lane_cy) * 2);
+      const uint32_t *mid = a.r_in + t_mid * kTileWords + in_tile;
+      const bool left_in = row_in && bx > 0, right_in = row_in && bx + 1 < a.BX;
+      const uint32_t w0 = (left_in ? mid - kTileWords : a.r_in)[1], w3 = (right_in ? mid + kTileWords : a.r_in)[0];
+      const uint2 w12 = *reinterpret_cast<const uint2 *>(mid);
+      L.cur[i][0] = left_in ? w0 : 0u;
+      L.cur[i][1] = row_in ? w12.x : 0u;
+      L.cur[i][2] = row_in ? w12.y : 0u;
+      L.cur[i][3] = right_in ? w3 : 0u;
 #pragma unroll
       for (int j = 0; j < 2; ++j) L.rec_any[i][j] = L.rec_b0[i][j] = L.rec_b1[i][j] = L.rec_b2[i][j] = 0u;
     }
@@ -838,12 +862,11 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
       for (int i = 0; i < kBitRows; ++i) {
         const int gz = zfirst + i;
         if (gz < 0 || gz >= a.Z) continue;
-        uint32_t *row = a.r_out + ((size_t)gz * a.Y + gy) * (size_t)a.WP;
-        const int gw = 2 * bx;
-        if (gw < a.WP) { row[gw] = L.cur[i][1]; any |= L.cur[i][1] != 0u; all &= L.cur[i][1] == valid[1]; }
-        if (gw + 1 < a.WP) { row[gw + 1] = L.cur[i][2]; any |= L.cur[i][2] != 0u; all &= L.cur[i][2] == valid[2]; }
+        const int cz = kBitRows * strip + i - kBitHalo;
+        *reinterpret_cast<uint2 *>(a.r_out + (size_t)b * kTileWords + (size_t)((cz * kBitCoreY + ((int)lane - kBitHalo)) * 2)) = uint2{L.cur[i][1], L.cur[i][2]};
+        any |= (L.cur[i][1] | L.cur[i][2]) != 0u;
+        all &= L.cur[i][1] == valid[1] && L.cur[i][2] == valid[2];  // a word beyond the volume: 0 == 0
         if (L.cur[i][1] | L.cur[i][2]) {  // words beyond the volume are zero (valid mask)
-          const int cz = kBitRows * strip + i - kBitHalo;
           atomicMin(&s_box[2], cz);
           atomicMax(&s_box[3], cz);
         }
@@ -952,13 +975,14 @@ hipError_t launch_sdfbit_events(const SdfArgs &a, uint32_t *ev, int32_t WP, hipS
 
 hipError_t launch_sdfbit_seed_init(const SdfBitArgs &a, int32_t max_iterations, hipStream_t s) {
   const size_t n_rows = (size_t)a.Y * (size_t)a.Z;
-  hipLaunchKernelGGL(k_sdfbit_seed, sdfbit_row_grid((uint32_t)a.WP, n_rows), dim3(256), 0, s, a.ev, a.r_out, a.X, a.Y, a.Z, a.WP, a.presence);
+  const SdfBitTiles tiles{a.BX, a.BY, a.core_z};
+  hipLaunchKernelGGL(k_sdfbit_seed, sdfbit_row_grid((uint32_t)a.WP, n_rows), dim3(256), 0, s, a.ev, a.r_out, a.X, a.Y, a.Z, a.WP, a.presence, tiles);
   if ((a.X % 16) == 0 && max_iterations >= 1) {
     hipLaunchKernelGGL(k_sdfbit_init16, sdfbit_row_grid((uint32_t)(a.X / 16), n_rows), dim3(256), 0, s, a.ev, (const uint32_t *)a.r_out, a.sdf, a.X, a.Y,
-                       a.Z, a.WP, max_iterations);
+                       a.Z, a.WP, max_iterations, tiles);
   } else {
     hipLaunchKernelGGL(k_sdfbit_init, dim3(((unsigned)a.X + 255u) / 256u, (unsigned)a.Y, (unsigned)a.Z), dim3(256), 0, s, a.ev, (const uint32_t *)a.r_out,
-                       a.sdf, a.X, a.Y, a.Z, a.WP, max_iterations);
+                       a.sdf, a.X, a.Y, a.Z, a.WP, max_iterations, tiles);
   }
   return hipGetLastError();
 }
