@@ -437,8 +437,9 @@ __global__ __launch_bounds__(256) void k_sdfbit_events(const SdfArgs a, uint32_t
   }
 }
 
-// the same for rule tables without `gradient` on rows of a multiple of 8 voxels: a lane classifies the 8 voxels of one
-// 16-byte load and writes their byte of the bit image (387 -> 75 us at 512^3: the per-voxel kernel was issue-bound)
+// the same for rule tables on rows of a multiple of 8 voxels: a lane classifies the 8 voxels of one 16-byte load (with `gradient`
+// rules: plus the four neighbouring rows' loads) and writes their byte of the bit image (387 -> 57 us at 512^3 without
+// gradient rules: the per-voxel kernel was issue-bound)
 // (row, unit) of a thread for kernels that work on `units` items per (y, z) row: blockIdx.x counts groups of rows
 // (rows_per_block = 256 / units when a row has fewer than 256 units), blockIdx.y chunks of 256 units within a row
 __device__ __forceinline__ bool sdfbit_row_unit(uint32_t units, size_t n_rows, size_t &row, uint32_t &unit) {
@@ -459,26 +460,59 @@ static dim3 sdfbit_row_grid(uint32_t units, size_t n_rows) {
   return dim3((unsigned)((n_rows + rows_per_block - 1u) / rows_per_block), 1u);
 }
 
+template <bool USE_GRAD>
 __global__ __launch_bounds__(256) void k_sdfbit_events8(const SdfArgs a, uint8_t *__restrict__ ev_bytes, int32_t WP) {
   size_t row;
   uint32_t unit;
-  if (!sdfbit_row_unit((uint32_t)WP * 4u, (size_t)a.Y * (size_t)a.Z, row, unit)) return;
+  const size_t n_rows = (size_t)a.Y * (size_t)a.Z;
+  if (!sdfbit_row_unit((uint32_t)WP * 4u, n_rows, row, unit)) return;
   const int x0 = (int)unit * 8;
   uint32_t bits = 0u;
   if (x0 < a.X) {  // X is a multiple of 8: all eight voxels exist
-    const uint4 q = *reinterpret_cast<const uint4 *>(a.volume + row * (size_t)a.X + (size_t)x0);
-    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-    int value[8];
+    const int16_t *own = a.volume + row * (size_t)a.X + (size_t)x0;
+    auto load8 = [](const int16_t *p, int (&v)[8]) {
+      const uint4 q = *reinterpret_cast<const uint4 *>(p);
+      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-    for (int h = 0; h < 8; ++h) value[h] = (int)(int16_t)(w[h >> 1] >> (16 * (h & 1)));
+      for (int h = 0; h < 8; ++h) v[h] = (int)(int16_t)(w[h >> 1] >> (16 * (h & 1)));
+    };
+    int value[8], gradient[8];
+    load8(own, value);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) gradient[h] = 0;
+    if (USE_GRAD) {
+      // utility_filter.cl:2-35 at the voxel: central differences of the six neighbours (border texel 0), the float length
+      // converted to short (signed_distance_field.cl:13-20) -- event_at<true> for eight voxels of one row
+      const int z = (int)(row / (size_t)a.Y), y = (int)(row - (size_t)z * (size_t)a.Y);
+      int ym[8], yp[8], zm[8], zp[8];
+#pragma unroll
+      for (int h = 0; h < 8; ++h) ym[h] = yp[h] = zm[h] = zp[h] = 0;
+      if (y > 0) load8(own - a.X, ym);
+      if (y + 1 < a.Y) load8(own + a.X, yp);
+      if (z > 0) load8(own - (size_t)a.X * (size_t)a.Y, zm);
+      if (z + 1 < a.Z) load8(own + (size_t)a.X * (size_t)a.Y, zp);
+      const int left = x0 > 0 ? (int)own[-1] : 0, right = x0 + 8 < a.X ? (int)own[8] : 0;
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const float dx = (float)((h < 7 ? value[h < 7 ? h + 1 : 7] : right) - (h > 0 ? value[h > 0 ? h - 1 : 0] : left));
+        const float dy = (float)(yp[h] - ym[h]);
+        const float dz = (float)(zp[h] - zm[h]);
+        gradient[h] = (int)(short)f2i(sqrtf((dx * dx + dy * dy) + dz * dz));
+      }
+    }
     // tf_eval for the eight voxels at once, the rule (one scalar load of its bounds) in the outer loop: the first matching
     // rule decides, a terminal rule that does not match decides "no event" (render_device.hpp: tf_eval)
     uint32_t undecided = 0xFFu;
     for (int k = 0; k < a.tf.n && undecided; ++k) {
-      const int lo = a.tf.rules[k].v_lo, hi = a.tf.rules[k].v_hi;
+      const int lo = a.tf.rules[k].v_lo, hi = a.tf.rules[k].v_hi, g_lo = a.tf.rules[k].g_lo, g_hi = a.tf.rules[k].g_hi;
+      const bool use_g = USE_GRAD && (a.tf.rules[k].flags & TF_USE_GRADIENT);
       uint32_t m = 0u;
 #pragma unroll
-      for (int h = 0; h < 8; ++h) m |= (value[h] >= lo && value[h] <= hi) ? (1u << h) : 0u;
+      for (int h = 0; h < 8; ++h) {
+        bool hit = value[h] >= lo && value[h] <= hi;
+        if (use_g) hit = hit && gradient[h] >= g_lo && gradient[h] <= g_hi;
+        m |= hit ? (1u << h) : 0u;
+      }
       bits |= m & undecided;
       undecided &= ~m;
       if (a.tf.rules[k].flags & TF_TERMINAL) undecided = 0u;
@@ -961,8 +995,12 @@ void sdfbit_block_grid(int X, int Y, int Z, int waves, int32_t *BX, int32_t *BY,
 }
 
 hipError_t launch_sdfbit_events(const SdfArgs &a, uint32_t *ev, int32_t WP, hipStream_t s) {
-  if (!a.tf.uses_gradient && !a.cls_in && (a.X % 8) == 0) {
-    hipLaunchKernelGGL(k_sdfbit_events8, sdfbit_row_grid((uint32_t)WP * 4u, (size_t)a.Y * (size_t)a.Z), dim3(256), 0, s, a, (uint8_t *)ev, WP);
+  if (!a.cls_in && (a.X % 8) == 0) {
+    const dim3 grid8 = sdfbit_row_grid((uint32_t)WP * 4u, (size_t)a.Y * (size_t)a.Z);
+    if (a.tf.uses_gradient)
+      hipLaunchKernelGGL(k_sdfbit_events8<true>, grid8, dim3(256), 0, s, a, (uint8_t *)ev, WP);
+    else
+      hipLaunchKernelGGL(k_sdfbit_events8<false>, grid8, dim3(256), 0, s, a, (uint8_t *)ev, WP);
     return hipGetLastError();
   }
   const dim3 grid(((unsigned)a.X + 255u) / 256u, (unsigned)a.Y, (unsigned)a.Z);

@@ -136,3 +136,12 @@ def gpu_ctx_sdf_waves16():
     ctx = _ctx_with_env({"CLWH_TUNE_SDFBIT_WAVES": "16"})
     yield ctx
     ctx.destroy()
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx_half_grid():
+    """k_bounce on half the persistent grid (CLWH_TUNE_BLOCKS=1024): what bench.py asks for when two frame jobs of a multi-rank run
+    are in flight"""
+    ctx = _ctx_with_env({"CLWH_TUNE_BLOCKS": "1024"})
+    yield ctx
+    ctx.destroy()

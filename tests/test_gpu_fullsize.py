@@ -109,6 +109,22 @@ def test_job_level_properties_without_the_oracle(full):
         assert np.array_equal(cache[:, :3].sum(axis=0), eight[:, :3].astype(np.int64).sum(axis=0))
 
 
+def test_half_grid_rank_share_equals_the_default_grid(full, gpu_ctx_half_grid):
+    """bench.py runs a rank's share of a multi-rank frame job with k_bounce on half the persistent grid (a placement knob): the
+    rank-0 share of a 2-rank split, 64 fused passes, must give the same image-space sums bit for bit -- and they must be the
+    default grid's (the launch is scheduled as a long one either way, but over different queues and refill orders)."""
+    vol, env, tf, pos, d = full["vol"], full["env"], full["tf"], full["pos"], full["d"]
+    seeds = scene.glibc_rand(64)
+    sums = []
+    for ctx in (full["g"].ctx, gpu_ctx_half_grid):
+        g = GpuScene(ctx, vol, full["sdf"], env, tf, (W, H), world=2)
+        g.render(pos, d, None, mode=ffi.ACCUM_IMAGE_SPACE, seeds=seeds, debug=False, write_frame=False, rank=0)
+        sums.append(g.accum[0].pull(np.float32).reshape(-1, 4).copy())
+        g.release()
+    assert sums[0][:, 3].max() == 64.0
+    assert np.array_equal(sums[0], sums[1])
+
+
 def test_large_volume_64bit_indexing(gpu_ctx, orc):
     """1024^3: the voxel cache (8.6 GB) and the packed records (4 GiB + 1 GiB) need 64-bit byte offsets;
     the reference itself cannot run here (its int index overflows above ~812^3, utility.cl:21, SURVEY
