@@ -180,7 +180,8 @@ struct SdfBitArgs {
   const uint32_t *r_in;    // reached set after r0 layers
   uint32_t *r_out;         // reached set after r0 + steps layers (core rows of the active blocks)
   uint8_t *state;          // per block of sdfbit_block_grid: 0 empty, 1 some, 2 complete (just now), 3 complete in both buffers
-  unsigned long long *bbox; // per block with state != 0: box around the core's reached voxels (sdf_kernels.hip: sdfbit_pack_bbox)
+  uint8_t *wake;           // per block: launch index + 1 for which a neighbour's reached voxels came within 8 voxels of its core
+  int32_t launch;          // index of this launch (8 layers each)
   int32_t *presence;       // [D] != 0: some voxel lies D corner moves from the nearest seed; [0]: a seed exists
   int32_t X, Y, Z, WP;
   int32_t BX, BY, BZ, core_z;  // blocks of 64 x 48 x core_z voxels (sdfbit_block_grid)

@@ -1020,19 +1020,20 @@ static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settl
   // blocks, per-launch {count, head}, the regions' bounding boxes and states
   const size_t tiled = n_blocks * (size_t)(2 * 48 * a.core_z);
   const size_t small = n_blocks + 2 * (size_t)(n_launches + 1);
-  const size_t scratch_words = words + 2 * tiled + small + (small & 1u) + 2 * n_blocks;
-  int rc = grow(ctx, (void **)&ctx->sdf_bits, &ctx->sdf_bits_bytes, scratch_words * sizeof(uint32_t) + n_blocks);
+  const size_t scratch_words = words + 2 * tiled + small;
+  int rc = grow(ctx, (void **)&ctx->sdf_bits, &ctx->sdf_bits_bytes, scratch_words * sizeof(uint32_t) + 2 * n_blocks);
   if (rc != CLWH_OK) return rc;
-  uint32_t *ev = ctx->sdf_bits, *reached[2] = {ctx->sdf_bits + words, ctx->sdf_bits + words + tiled};
+  uint32_t *ev = ctx->sdf_bits, *reached[2] = {ctx->sdf_bits + words, ctx->sdf_bits + words + tiled};  // words and tiled are even: 8-byte aligned
   uint32_t *list = ctx->sdf_bits + words + 2 * tiled, *queue = list + n_blocks;
-  a.bbox = reinterpret_cast<unsigned long long *>(ctx->sdf_bits + scratch_words - 2 * n_blocks);  // 8-byte aligned: words and tiled are even, the pad word above
   a.sdf = b.ping;
   a.ev = ev;
   a.list = list;
   a.state = reinterpret_cast<uint8_t *>(ctx->sdf_bits + scratch_words);
+  a.wake = a.state + n_blocks;
   a.presence = ctx->sdf_counters;
   HIP_TRY(hipMemsetAsync(reached[0], 0, 2 * tiled * sizeof(uint32_t), ctx->stream));  // rows nobody ever writes (beyond the volume, never reached) read as empty in both buffers
   HIP_TRY(hipMemsetAsync(queue, 0, 2 * (size_t)(n_launches + 1) * sizeof(uint32_t), ctx->stream));
+  HIP_TRY(hipMemsetAsync(a.wake, 0, n_blocks, ctx->stream));
   HIP_TRY(launch_sdfbit_events(b, ev, a.WP, ctx->stream));
   a.r_out = reached[0];
   HIP_TRY(launch_sdfbit_seed_init(a, b.max_iterations, ctx->stream));
@@ -1047,6 +1048,7 @@ static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settl
   int t = 0;
   for (int r0 = 0; r0 < total; r0 += 8, ++t) {
     a.r0 = r0;
+    a.launch = t;
     a.steps = std::min(8, total - r0);
     a.r_in = reached[t & 1];
     a.r_out = reached[(t + 1) & 1];

@@ -609,12 +609,19 @@ constexpr int kBitCoreY = 48, kBitHalo = 8, kBitRows = 4;  // a wave = 64 rows a
 // a block = NW waves (8 or 16) = NW strips of 4 z-rows: region z = 4 NW, core z = 4 NW - 16 (SdfBitArgs::core_z)
 
 // block state: 0 = no reached voxel in the core, 1 = some, 2 = all (just now: the other bit buffer is not complete yet), 3 = all, both buffers.
-// bbox: the box (relative to the core, inclusive) around the core's reached voxels: x0 | x1 << 8 | y0 << 16 | y1 << 24 | z0 << 32 | z1 << 40
-__device__ __forceinline__ unsigned long long sdfbit_pack_bbox(uint32_t orx0, uint32_t orx1, int y0, int y1, int z0, int z1) {
-  const unsigned long long orx = (unsigned long long)orx0 | ((unsigned long long)orx1 << 32);
-  const int x0 = __ffsll((long long)orx) - 1, x1 = 63 - __clzll((long long)orx);
-  return (unsigned long long)(unsigned)x0 | ((unsigned long long)(unsigned)x1 << 8) | ((unsigned long long)(unsigned)y0 << 16) |
-         ((unsigned long long)(unsigned)y1 << 24) | ((unsigned long long)(unsigned)z0 << 32) | ((unsigned long long)(unsigned)z1 << 40);
+// A region with reached voxels wakes the EMPTY regions among its 26 neighbours whose core lies within 8 voxels (Chebyshev; a corner move
+// changes every coordinate by at most one) of the box around its reached voxels: lane q < 27 stamps neighbour q for the launch `stamp - 1`.
+// No loads: the list kernel then needs one byte per region instead of up to 27 dependent state / box reads.
+__device__ __forceinline__ void sdfbit_wake_neighbours(const SdfBitArgs &a, int bx, int by, int bz, int x0, int x1, int y0, int y1, int z0, int z1,
+                                                       unsigned q, uint8_t stamp) {
+  if (q >= 27u) return;
+  const int nx = bx + (int)(q % 3u) - 1, ny = by + (int)((q / 3u) % 3u) - 1, nz = bz + (int)(q / 9u) - 1;
+  if (nx < 0 || ny < 0 || nz < 0 || nx >= a.BX || ny >= a.BY || nz >= a.BZ) return;
+  const int cx0 = nx * 64, cx1 = min(cx0 + 63, a.X - 1), cy0 = ny * kBitCoreY, cy1 = min(cy0 + kBitCoreY - 1, a.Y - 1), cz0 = nz * a.core_z,
+            cz1 = min(cz0 + a.core_z - 1, a.Z - 1);
+  const int rx0 = bx * 64 + x0, rx1 = bx * 64 + x1, ry0 = by * kBitCoreY + y0, ry1 = by * kBitCoreY + y1, rz0 = bz * a.core_z + z0, rz1 = bz * a.core_z + z1;
+  const int gx = max(max(rx0 - cx1, cx0 - rx1), 0), gy = max(max(ry0 - cy1, cy0 - ry1), 0), gz = max(max(rz0 - cz1, cz0 - rz1), 0);
+  if (gx <= kBitHalo && gy <= kBitHalo && gz <= kBitHalo) a.wake[((size_t)nz * a.BY + ny) * a.BX + nx] = stamp;
 }
 
 __global__ __launch_bounds__(64) void k_sdfbit_state(const SdfBitArgs a) {
@@ -646,9 +653,10 @@ __global__ __launch_bounds__(64) void k_sdfbit_state(const SdfBitArgs a) {
     z0 = min(z0, __shfl_xor(z0, off)); z1 = max(z1, __shfl_xor(z1, off));
   }
   const bool w_any = __ballot(any) != 0ull, w_all = __ballot(!all) == 0ull;
-  if (lane == 0u) {
-    a.state[b] = w_all ? 2 : (w_any ? 1 : 0);
-    if (w_any) a.bbox[b] = sdfbit_pack_bbox(orx[0], orx[1], y0, y1, z0, z1);
+  if (lane == 0u) a.state[b] = w_all ? 2 : (w_any ? 1 : 0);
+  if (w_any) {
+    const unsigned long long orx64 = (unsigned long long)orx[0] | ((unsigned long long)orx[1] << 32);
+    sdfbit_wake_neighbours(a, bx, by, bz, __ffsll((long long)orx64) - 1, 63 - __clzll((long long)orx64), y0, y1, z0, z1, lane, 1);  // launch 0
   }
 }
 
@@ -656,36 +664,22 @@ __global__ __launch_bounds__(64) void k_sdfbit_state(const SdfBitArgs a) {
 __device__ __forceinline__ uint32_t sdfbit_lane_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true); }
 __device__ __forceinline__ uint32_t sdfbit_lane_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xF, 0xF, true); }
 
-// the blocks that can change in the next launch: not complete in both buffers, and a reached voxel within 8 voxels (Chebyshev; a
-// corner move changes every coordinate by at most one) of their core -- for an empty block: in a neighbour's bounding box.
+// the blocks that can change in the next launch: a front inside, complete since the last launch (the other buffer is still to be
+// brought up to date), or empty and woken for this launch by a neighbour (sdfbit_wake_neighbours).
 // (The first version woke an empty block as soon as a neighbour held ANY reached voxel, up to 16 launches before the front
-// arrived: two thirds of the regions a launch worked on could not change.)
+// arrived; the second read the 27 neighbours' states and boxes here: 11 us per launch of dependent loads.)
 __device__ __forceinline__ void sdfbit_build_list(const SdfBitArgs &a, uint32_t *count, int first, int stride) {
   const int n_blocks = a.BX * a.BY * a.BZ;
   const int rounds = (n_blocks + stride - 1) / stride;  // every wave runs the same number of rounds (ballots below)
+  const uint8_t stamp = (uint8_t)(a.launch + 1);
   for (int r = 0; r < rounds; ++r) {
     const int b = first + r * stride;
     bool active = false, complete = false;
     if (b < n_blocks) {
       const int st = a.state[b];
-      active = st == 1 || st == 2;
+      const uint8_t wk = a.wake[b];
+      active = st == 1 || st == 2 || (st == 0 && wk == stamp);
       complete = st == 2;
-      if (st == 0) {
-        const int bx = b % a.BX, by = (b / a.BX) % a.BY, bz = b / (a.BX * a.BY);
-        const int cx0 = bx * 64, cx1 = min(cx0 + 63, a.X - 1), cy0 = by * kBitCoreY, cy1 = min(cy0 + kBitCoreY - 1, a.Y - 1), cz0 = bz * a.core_z,
-                  cz1 = min(cz0 + a.core_z - 1, a.Z - 1);
-        for (int q = 0; q < 27 && !active; ++q) {
-          const int nx = bx + q % 3 - 1, ny = by + (q / 3) % 3 - 1, nz = bz + q / 9 - 1;
-          if (nx < 0 || ny < 0 || nz < 0 || nx >= a.BX || ny >= a.BY || nz >= a.BZ) continue;
-          const size_t nb = ((size_t)nz * a.BY + ny) * a.BX + nx;
-          if (a.state[nb] == 0) continue;
-          const unsigned long long bb = a.bbox[nb];
-          const int rx0 = nx * 64 + (int)(bb & 0xFF), rx1 = nx * 64 + (int)((bb >> 8) & 0xFF), ry0 = ny * kBitCoreY + (int)((bb >> 16) & 0xFF),
-                    ry1 = ny * kBitCoreY + (int)((bb >> 24) & 0xFF), rz0 = nz * a.core_z + (int)((bb >> 32) & 0xFF), rz1 = nz * a.core_z + (int)((bb >> 40) & 0xFF);
-          const int gx = max(max(rx0 - cx1, cx0 - rx1), 0), gy = max(max(ry0 - cy1, cy0 - ry1), 0), gz = max(max(rz0 - cz1, cz0 - rz1), 0);
-          active = gx <= kBitHalo && gy <= kBitHalo && gz <= kBitHalo;
-        }
-      }
     }
     const unsigned long long m = __ballot(active);
     if (m == 0ull) continue;
@@ -837,6 +831,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
         }
       }
       if (tid == 0u) a.state[b] = 3;
+      sdfbit_wake_neighbours(a, bx, by, bz, 0, 63, 0, kBitCoreY - 1, 0, kCoreZ - 1, tid, (uint8_t)(a.launch + 2));
       continue;
     }
 
@@ -979,9 +974,13 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
       atomicAdd(&a.timing[4], tq4 - tq3); atomicAdd(&a.timing[5], wall_clock64() - tq4); atomicAdd(&a.timing[6], interior ? 1ull : 0ull);
     }
 #endif
+    if (s_any) {
+      const unsigned long long orx64 = (unsigned long long)s_orx[0] | ((unsigned long long)s_orx[1] << 32);
+      sdfbit_wake_neighbours(a, bx, by, bz, __ffsll((long long)orx64) - 1, 63 - __clzll((long long)orx64), s_box[0], s_box[1], s_box[2], s_box[3], tid,
+                             (uint8_t)(a.launch + 2));  // for the next launch
+    }
     if (tid == 0u) {
       a.state[b] = s_all ? 2 : (s_any ? 1 : 0);
-      if (s_any) a.bbox[b] = sdfbit_pack_bbox(s_orx[0], s_orx[1], s_box[0], s_box[1], s_box[2], s_box[3]);
       for (uint32_t m = s_steps; m; m &= m - 1u) a.presence[a.r0 + __ffs((int)m)] = 1;  // layer r0 + k + 1 settled something
     }
   }
