@@ -90,3 +90,31 @@ def test_apply_clip(gpu_ctx):
     for m in (v, dst, b_start, b_len):
         m.release()
     k.release()
+
+
+@pytest.mark.parametrize("dims", [(192, 160, 144), (200, 170, 150), (2056, 6, 5)])
+def test_stats_and_histogram_at_scale(gpu_ctx, dims):
+    """fetch_stats and tf_sort_values are persistent grids (a lane takes eight voxels, 16-byte loads when the row length allows; the
+    histogram counts into a per-block hash table in LDS): volumes with more work items than blocks, rows longer than a block's chunk,
+    both load paths -- every statistic and every one of the 500 x 500 bins against the numpy restatement"""
+    vol = scene.phantom(max(dims[:3]) if max(dims) < 1000 else 64, dims=dims)
+    v = gpu_ctx.image_from(vol)
+    ev = lambda g, l=8: (g + l - 1) // l * l  # noqa: E731
+    G = [ev(dims[0]), ev(dims[1]), ev(dims[2])]
+    stats = gpu_ctx.buffer_from(INIT)
+    k = gpu_ctx.kernel("reference_volume_figures.cl", "fetch_stats")
+    k.launch(G, [4, 4, 4], v, stats)
+    st = stats.pull()
+    want = orc_volume.fetch_stats(vol)
+    assert np.array_equal(st[:4], want[:4]), (st, want)
+    W = H = 500
+    bins = gpu_ctx.buffer_from(np.zeros(W * H, np.uint32))
+    kh = gpu_ctx.kernel("histogram.cl", "tf_sort_values")
+    kh.launch(G, [4, 4, 4], v, bins, np.uint32(W), np.uint32(H), float(st[0]), float(st[1]), float(st[2]), float(st[3]))
+    got = bins.pull()
+    want_bins = orc_volume.tf_sort_values(vol, W, H, float(st[0]), float(st[1]), float(st[2]), float(st[3]))
+    assert np.array_equal(got.reshape(-1), np.asarray(want_bins).reshape(-1).astype(np.uint32))
+    assert int(got.sum()) > 0.9 * vol.size   # only the voxels on the top row / column of the frame fall outside
+    for m in (v, stats, bins):
+        m.release()
+    k.release(); kh.release()
