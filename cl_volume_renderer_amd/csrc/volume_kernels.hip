@@ -68,18 +68,17 @@ __device__ __forceinline__ float gradient_length8(const Voxels8 &o, int h) {
   return sqrtf((gx * gx + gy * gy) + gz * gz);
 }
 
-// A persistent grid walks (row, 2048-voxel chunk) work items, a lane eight voxels at a time; a block reduces through cross-lane
+// A persistent grid walks the volume, a lane eight consecutive voxels of a row at a time; a block reduces through cross-lane
 // operations and LDS and touches the four statistics only if it improves them.  (The first version ran one block per 256 voxels with
 // four same-address atomics each: 2 M atomics serialised at one L2 channel, 24 ms at 512^3 for a 0.27 GB stream.)
 __global__ __launch_bounds__(256) void k_fetch_stats(const int16_t *__restrict__ vol, int X, int Y, int Z, int32_t *stats) {
   __shared__ int s_red[4][4];
   int vmin = 2147483647, vmax = -2147483647 - 1, gmin = 2147483647, gmax = -2147483647 - 1;
-  const unsigned chunks = ((unsigned)X + 2047u) / 2048u;
-  const size_t n_work = (size_t)Y * (size_t)Z * chunks;
-  for (size_t work = blockIdx.x; work < n_work; work += gridDim.x) {
-    const size_t row = work / chunks;
-    const int x0 = ((int)(work - row * chunks) * 256 + (int)threadIdx.x) * 8;
-    if (x0 >= X) continue;
+  // work item = eight consecutive voxels of a row; a block takes 256 consecutive items (several rows when rows are short)
+  const size_t per_row = ((size_t)X + 7u) / 8u, n_items = (size_t)Y * (size_t)Z * per_row;
+  for (size_t item = (size_t)blockIdx.x * 256u + threadIdx.x; item < n_items; item += (size_t)gridDim.x * 256u) {
+    const size_t row = item / per_row;
+    const int x0 = (int)(item - row * per_row) * 8;
     const int z = (int)(row / (size_t)Y), y = (int)(row - (size_t)z * (size_t)Y);
     Voxels8 o;
     load_voxels8(vol, X, Y, Z, x0, y, z, o);
@@ -208,12 +207,11 @@ __global__ __launch_bounds__(256) void k_tf_sort_values(const int16_t *__restric
   };
   const float value_range = max_value - min_value;
   const float gradient_range = max_gradient - min_gradient;
-  const unsigned chunks = ((unsigned)X + 2047u) / 2048u;
-  const size_t n_work = (size_t)Y * (size_t)Z * chunks;
-  for (size_t work = blockIdx.x; work < n_work; work += gridDim.x) {
-    const size_t row = work / chunks;
-    const int x0 = ((int)(work - row * chunks) * 256 + (int)threadIdx.x) * 8;
-    if (x0 >= X) continue;
+  // work item = eight consecutive voxels of a row; a block takes 256 consecutive items (several rows when rows are short)
+  const size_t per_row = ((size_t)X + 7u) / 8u, n_items = (size_t)Y * (size_t)Z * per_row;
+  for (size_t item = (size_t)blockIdx.x * 256u + threadIdx.x; item < n_items; item += (size_t)gridDim.x * 256u) {
+    const size_t row = item / per_row;
+    const int x0 = (int)(item - row * per_row) * 8;
     const int z = (int)(row / (size_t)Y), y = (int)(row - (size_t)z * (size_t)Y);
     Voxels8 o;
     load_voxels8(vol, X, Y, Z, x0, y, z, o);
@@ -274,8 +272,8 @@ hipError_t launch_bilateral_filter(const int16_t *src, int X, int Y, int Z, int1
 }
 
 static unsigned persistent_grid(int X, int Y, int Z) {
-  const size_t n_work = (size_t)Y * (size_t)Z * (((size_t)X + 2047u) / 2048u);
-  return (unsigned)std::min<size_t>(n_work, 2048u);
+  const size_t n_items = (size_t)Y * (size_t)Z * (((size_t)X + 7u) / 8u);
+  return (unsigned)std::min<size_t>((n_items + 255u) / 256u, 2048u);
 }
 
 hipError_t launch_fetch_stats(const int16_t *vol, int X, int Y, int Z, int32_t *stats, hipStream_t s) {
