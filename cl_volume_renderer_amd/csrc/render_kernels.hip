@@ -72,26 +72,58 @@ __device__ __forceinline__ unsigned lane_id() { return prefix_count(~0ull); }
 // in LDS; the central differences and the class come from there; every wave then writes whole 4x4x4 sub-bricks (512
 // contiguous bytes of hit records, 64 of step bytes).  The first version let each wave gather its sub-brick's rows and
 // the six taps straight from global memory: 8-byte pieces of 128-byte lines, 2.1 GB fetched for a 0.27 GB volume.
-constexpr int kRepackX = 32, kRepackRX = kRepackX + 2;  // voxels per block along x, with halo
+constexpr int kRepackX = 32;        // voxels per block along x
+constexpr int kRepackPitch = 48;    // LDS row: 7 unused shorts, x0 - 1, the 32 voxels from a 16-byte aligned offset, x0 + 32, padding
+constexpr int kRepackX0 = 8;        // index of voxel x0 in a row
 __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
-  __shared__ int16_t s_val[10][10][kRepackRX + 2];  // [z][y][x] values with halo (row padded to an even count)
-  __shared__ int8_t s_sdf[8][8][kRepackX];
+  __shared__ __attribute__((aligned(16))) int16_t s_val[10][10][kRepackPitch];  // [z][y][kRepackX0 + lx], lx = -1 .. 32: values with halo
+  __shared__ __attribute__((aligned(16))) int8_t s_sdf[8][8][kRepackX];
   const int x0 = (int)blockIdx.x * kRepackX, y0 = (int)blockIdx.y * 8, z0 = (int)blockIdx.z * 8;
   const unsigned tid = threadIdx.x;
-  for (unsigned i = tid; i < 10u * 10u * (unsigned)kRepackRX; i += 256u) {
-    const int rx = (int)(i % (unsigned)kRepackRX), ry = (int)((i / (unsigned)kRepackRX) % 10u), rz = (int)(i / (10u * (unsigned)kRepackRX));
-    const int x = x0 - 1 + rx, y = y0 - 1 + ry, z = z0 - 1 + rz;
-    int16_t v = 0;  // border texel (utility_filter.cl:2-35 reads with CLK_ADDRESS_CLAMP: 0 outside)
-    if ((unsigned)x < (unsigned)a.X && (unsigned)y < (unsigned)a.Y && (unsigned)z < (unsigned)a.Z)
-      v = a.volume[((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x];
-    s_val[rz][ry][rx] = v;
-  }
-  for (unsigned i = tid; i < 8u * 8u * (unsigned)kRepackX; i += 256u) {
-    const int rx = (int)(i % (unsigned)kRepackX), ry = (int)((i / (unsigned)kRepackX) % 8u), rz = (int)(i / (8u * (unsigned)kRepackX));
-    const int x = x0 + rx, y = y0 + ry, z = z0 + rz;
-    int8_t v = 0;
-    if (x < a.X && y < a.Y && z < a.Z) v = a.sdf[((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x];
-    s_sdf[rz][ry][rx] = v;
+  if ((a.X & 15) == 0 && x0 + kRepackX <= a.X && ((reinterpret_cast<uintptr_t>(a.volume) | reinterpret_cast<uintptr_t>(a.sdf)) & 15u) == 0u) {
+    // rows of a multiple of 16 voxels, box inside the volume along x: a lane moves 16 bytes (the staging loop below spent more
+    // instructions on its per-voxel index arithmetic than the classification that follows)
+    for (unsigned i = tid; i < 10u * 10u * 4u; i += 256u) {
+      const unsigned row = i >> 2, c = i & 3u;
+      const int ry = (int)(row % 10u), rz = (int)(row / 10u);
+      const int y = y0 - 1 + ry, z = z0 - 1 + rz;
+      uint4 v = uint4{0u, 0u, 0u, 0u};  // border texel (utility_filter.cl:2-35 reads with CLK_ADDRESS_CLAMP: 0 outside)
+      int16_t left = 0, right = 0;
+      if ((unsigned)y < (unsigned)a.Y && (unsigned)z < (unsigned)a.Z) {
+        const int16_t *src = a.volume + ((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x0;
+        v = *reinterpret_cast<const uint4 *>(src + 8 * c);
+        if (c == 0u && x0 > 0) left = src[-1];
+        if (c == 3u && x0 + kRepackX < a.X) right = src[kRepackX];
+      }
+      *reinterpret_cast<uint4 *>(&s_val[rz][ry][kRepackX0 + 8 * (int)c]) = v;
+      if (c == 0u) s_val[rz][ry][kRepackX0 - 1] = left;
+      if (c == 3u) s_val[rz][ry][kRepackX0 + kRepackX] = right;
+    }
+    if (tid < 8u * 8u * 2u) {
+      const unsigned row = tid >> 1, c = tid & 1u;
+      const int ry = (int)(row & 7u), rz = (int)(row >> 3);
+      const int y = y0 + ry, z = z0 + rz;
+      uint4 v = uint4{0u, 0u, 0u, 0u};
+      if (y < a.Y && z < a.Z) v = *reinterpret_cast<const uint4 *>(a.sdf + ((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x0 + 16u * c);
+      *reinterpret_cast<uint4 *>(&s_sdf[rz][ry][16 * (int)c]) = v;
+    }
+  } else {
+    constexpr unsigned kRX = kRepackX + 2;
+    for (unsigned i = tid; i < 10u * 10u * kRX; i += 256u) {
+      const int rx = (int)(i % kRX), ry = (int)((i / kRX) % 10u), rz = (int)(i / (10u * kRX));
+      const int x = x0 - 1 + rx, y = y0 - 1 + ry, z = z0 - 1 + rz;
+      int16_t v = 0;
+      if ((unsigned)x < (unsigned)a.X && (unsigned)y < (unsigned)a.Y && (unsigned)z < (unsigned)a.Z)
+        v = a.volume[((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x];
+      s_val[rz][ry][kRepackX0 - 1 + rx] = v;
+    }
+    for (unsigned i = tid; i < 8u * 8u * (unsigned)kRepackX; i += 256u) {
+      const int rx = (int)(i % (unsigned)kRepackX), ry = (int)((i / (unsigned)kRepackX) % 8u), rz = (int)(i / (8u * (unsigned)kRepackX));
+      const int x = x0 + rx, y = y0 + ry, z = z0 + rz;
+      int8_t v = 0;
+      if (x < a.X && y < a.Y && z < a.Z) v = a.sdf[((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x];
+      s_sdf[rz][ry][rx] = v;
+    }
   }
   __syncthreads();
   const unsigned wave = tid >> 6, lane = tid & 63u;
@@ -108,12 +140,13 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
     uint8_t q = 0u;
     uint32_t free_min = 255u;  // for the exit certificates: 0 = this voxel may be an event / has no positive SDF value
     if (x < a.X && y < a.Y && z < a.Z) {
-      const int value = s_val[lz + 1][ly + 1][lx + 1];
+      const int cx = kRepackX0 + lx;
+      const int value = s_val[lz + 1][ly + 1][cx];
       const int sd = s_sdf[lz][ly][lx];
       // central differences at the voxel's integer position, border 0 (utility_filter.cl:2-35)
-      const int dx = s_val[lz + 1][ly + 1][lx + 2] - s_val[lz + 1][ly + 1][lx];
-      const int dy = s_val[lz + 1][ly + 2][lx + 1] - s_val[lz + 1][ly][lx + 1];
-      const int dz = s_val[lz + 2][ly + 1][lx + 1] - s_val[lz][ly + 1][lx + 1];
+      const int dx = s_val[lz + 1][ly + 1][cx + 1] - s_val[lz + 1][ly + 1][cx - 1];
+      const int dy = s_val[lz + 1][ly + 2][cx] - s_val[lz + 1][ly][cx];
+      const int dz = s_val[lz + 2][ly + 1][cx] - s_val[lz][ly + 1][cx];
       int gradient = 0;
       if (a.tf.uses_gradient) {
         const float gx = (float)dx, gy = (float)dy, gz = (float)dz;
