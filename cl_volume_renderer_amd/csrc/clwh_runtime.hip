@@ -1017,7 +1017,7 @@ static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settl
   const int total = b.max_iterations - 2;
   const int n_launches = total > 0 ? (total + 7) / 8 : 0;
   // scratch: event bits (x-fastest rows), two reached-set buffers (tiled by region, padded to whole regions), the list of active
-  // blocks, per-launch {count, head}, the regions' bounding boxes and states
+  // blocks, per-launch {count, head}, the regions' states and wake stamps
   const size_t tiled = n_blocks * (size_t)(2 * 48 * a.core_z);
   const size_t small = n_blocks + 2 * (size_t)(n_launches + 1);
   const size_t scratch_words = words + 2 * tiled + small;

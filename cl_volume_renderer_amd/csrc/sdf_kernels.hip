@@ -884,7 +884,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
 #ifdef CLVR_SDFBIT_TIMING
     const unsigned long long tq3 = wall_clock64();
 #endif
-    // core rows back to the other bit buffer; the block's state and bounding box for the next launch
+    // core rows back to the other bit buffer; the block's state and the box around its reached voxels (whom to wake) for the next launch
     bool any = false, all = true;
     if (core_strip && core_lane && y_in) {
 #pragma unroll
