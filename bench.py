@@ -353,8 +353,8 @@ def main():
                     help="image: float4 per pixel + one all-gather (the headline); voxel: the reference's world-space "
                          "cache, one pass per launch, contributions exchanged pass by pass under the global 256-token rule")
     ap.add_argument("--seeds-per-launch", type=int, default=64, help="render passes fused into one launch (1..64)")
-    ap.add_argument("--frames-in-flight", type=int, default=2,
-                    help="consecutive frame jobs alternate between this many HIP streams (each with its own accumulation and "
+    ap.add_argument("--frames-in-flight", type=int, default=None,
+                    help="default 2 (3 from six ranks on): consecutive frame jobs alternate between this many HIP streams (each with its own accumulation and "
                          "frame buffers), so that the next frame's primary hits and first waves fill the GPU while the last "
                          "waves of the previous frame's persistent launch drain; 1 = strictly one frame after the other")
     args = ap.parse_args()
@@ -418,12 +418,15 @@ def main():
     if rank == 0:
         log("[bench] scene: phantom(%d) %.1fs" % (N, time.time() - t_setup))
 
-    # Two frame jobs in flight share the GPU.  A rank's share of a multi-GPU job is small (a few million items per launch); each of its
-    # two launches then does best on HALF the persistent grid: 2.12 -> 2.06 / 1.20 -> 1.11 / 0.76 -> 0.65 ms per job for 2 / 4 / 8
-    # ranks (tools/emulate_rank.py, profiles/r02_emulate_rank_grid_sweep.txt); the single-GPU job is indifferent and keeps the default.
-    # A placement knob, read when a context is created; results do not depend on it.
-    if world > 1 and max(1, args.frames_in_flight) >= 2:
-        os.environ.setdefault("CLWH_TUNE_BLOCKS", "1024")
+    # Frame jobs in flight share the GPU.  A rank's share of a multi-GPU job is small (a few million items per launch); each of its
+    # launches then does best on a SHARE of the persistent grid, so that they co-reside instead of queueing behind each other:
+    # 2.12 -> 2.06 / 1.20 -> 1.11 / 0.76 -> 0.65 ms per job for 2 / 4 / 8 ranks with two jobs in flight on 1024 blocks each, and 0.60 ms
+    # for 8 ranks with three jobs on 768 blocks each (tools/emulate_rank.py, profiles/r02_emulate_rank_grid_sweep.txt); the single-GPU
+    # job is indifferent and keeps the library default.  Placement knobs, read when a context is created; results do not depend on them.
+    if args.frames_in_flight is None:
+        args.frames_in_flight = 3 if world >= 6 else 2
+    if world > 1 and args.frames_in_flight >= 2:
+        os.environ.setdefault("CLWH_TUNE_BLOCKS", "1024" if args.frames_in_flight == 2 else "768")
     # everything below runs on torch's current stream so torch.cuda.synchronize() covers it
     ctx = ffi.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
     d_vol = ctx.image_from(vol)
