@@ -278,7 +278,7 @@ def run_voxel_multi(args, ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, 
     hit = torch.full((npx,), -1, dtype=torch.int64, device=dev)
     m_hit = ctx.wrap(hit.data_ptr(), npx * 8)
     seeds = scene.glibc_rand((WU + K + 1) * SPP)
-    xch = tiles.VoxelExchange(cache, world)
+    xch = tiles.VoxelExchange(cache, world, ctx=ctx)
 
     def frame_job(j):
         cache.zero_()

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libclwhip.so")
 
-SOURCES = ["clwh_runtime.hip", "render_kernels.hip", "sdf_kernels.hip", "volume_kernels.hip", "tf_parse.cpp", "tf_jit.cpp"]
+SOURCES = ["clwh_runtime.hip", "render_kernels.hip", "sdf_kernels.hip", "volume_kernels.hip", "exchange_kernels.hip", "tf_parse.cpp", "tf_jit.cpp"]
 HEADERS = ["clwh_internal.hpp", "device_math.hpp", "render_device.hpp", "packed_volume.hpp", "env_fast.hpp"]
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

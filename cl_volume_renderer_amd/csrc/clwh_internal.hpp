@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <map>
 #include <memory>
 #include <string>
@@ -83,6 +84,7 @@ struct RenderArgs {
   uint32_t fixup_capacity;
   uint32_t *sticky_flags;  // [0] fix-up overflow (outside the per-launch reset range: survives until the host reads it)
   uint32_t n_hits;         // host copy of counters[0], or an upper bound of it when n_hits_on_device
+  uint32_t n_hits_estimate;  // the likely count (the count itself once known): picks the scheduling class of the launch
   int32_t n_hits_on_device;  // 1: kernels read the hit count from counters[0] (no host round trip after k_primary)
   int32_t shading;         // clwh_shading
   int64_t *hit_index_out;  // optional, row-major over launch_w x launch_h
@@ -212,6 +214,30 @@ hipError_t launch_bilateral_filter(const int16_t *src, int X, int Y, int Z, int1
 hipError_t launch_apply_clip(const int16_t *src, int SX, int SY, int SZ, int16_t *dst, int DX, int DY, int DZ,
                              const uint32_t *start, const uint32_t *len, hipStream_t s);
 
+// ---- derived scene data (step bytes + hit records + per-brick minima + exit-certificate table), ONE copy per device however many
+// contexts (frame lanes, callers) render the same (volume content, SDF content, transfer function): contexts hold it by
+// shared_ptr and find it in a process-wide registry (clwh_runtime.hip); the memory goes when the last context lets go of it.
+struct PackedScene {
+  int device = 0;
+  uint8_t *data = nullptr;
+  size_t bytes = 0;
+  const void *vol = nullptr, *sdf = nullptr;
+  uint64_t vol_ver = 0, sdf_ver = 0;
+  TfDev tf{};
+  std::string tf_identity;   // opaque (hiprtc) transfer functions: the source text -- two sources may share a palette
+  int32_t macro_shift = 0;
+  uint64_t generation = 0;   // process-wide unique id of this content (part of the primary-hit key)
+  hipEvent_t ready = nullptr;  // recorded on the building stream after the last build kernel; adopters make their stream wait for it
+  bool stale = false;        // clwh_ctx_invalidate_derived: nobody adopts it any more
+  ~PackedScene();
+};
+
+// content version of a device allocation, shared by every clwh_mem that names the same device pointer (the owner and all
+// wraps): a push, a rebuild or clwh_mem_mark_dirty through ANY of them is seen by all
+struct VersionCell {
+  std::atomic<uint64_t> v{0};
+};
+
 }  // namespace clvr
 
 // ---- opaque handle layouts (host only)
@@ -257,6 +283,12 @@ struct clwh_ctx {
   bool primary_valid = false;
   uint32_t primary_n_hits = 0;
   bool primary_n_hits_known = false;  // false: the count of this camera's hits is only on the device so far
+  // the count travels to the host behind the camera's k_primary without anybody waiting for it: a 4-byte copy into page-locked
+  // memory + an event; later launches of the same camera pick it up once the event has completed (hipEventQuery)
+  uint32_t *host_n_hits = nullptr;
+  hipEvent_t n_hits_event = nullptr;
+  bool n_hits_in_flight = false;
+  uint32_t last_known_n_hits = 0;     // of any earlier camera of this context (0: none yet): sizes work buffers while the count is unknown
   struct PrimaryKey {
     float cam_pos[3], cam_dir[3];
     int32_t frame_w, frame_h, launch_w, launch_h, tile_rank, tile_world;
@@ -268,7 +300,6 @@ struct clwh_ctx {
     uint64_t env_version;
     int32_t env_w, env_h;
   } primary_key{};
-  uint64_t packed_generation = 0;
   float *bilateral_weights = nullptr;  // 13 x 17 tap weights of the bilateral volume filter (built on first use)
   int32_t *sdf_counters = nullptr;  // 160 ints: settled voxels per layer
   uint8_t *sdf_flags = nullptr;     // 4 x tiles bytes (current / next / being cleared / done)
@@ -278,13 +309,9 @@ struct clwh_ctx {
   int32_t tune_sdfbit_waves = 8;    // CLWH_TUNE_SDFBIT_WAVES: 8 or 16 waves per block of the bit-parallel build
   int32_t tune_sdfbit_grid = 512;   // CLWH_TUNE_SDFBIT_GRID: its persistent grid
   int32_t tune_sdf_front = 0;       // CLWH_TUNE_SDF=front: the byte-front build (one launch per layer) instead of the bit-parallel one
-  // derived packed volume (single entry, keyed by the source objects' identity + version and the TF)
-  uint8_t *packed = nullptr;  // hit records (8 B per voxel of the brick grid), the step bytes (1 B), the per-brick minima (4 B per brick), the macro-cell table
-  size_t packed_bytes = 0;
-  const void *packed_vol = nullptr, *packed_sdf = nullptr;
-  uint64_t packed_vol_ver = 0, packed_sdf_ver = 0;
-  clvr::TfDev packed_tf{};
-  bool packed_valid = false;
+  // derived packed volume: hit records (8 B per voxel of the brick grid), the step bytes (1 B), the per-brick minima (4 B per
+  // brick), the macro-cell table -- shared with every other context of the device that renders the same scene
+  std::shared_ptr<clvr::PackedScene> scene;
 
   // timing: one HIP event pair per clwh_render, recorded on the context's stream around the
   // dominant kernel and read back (without a sync per pass) by clwh_ctx_timing_read
@@ -304,8 +331,12 @@ struct clwh_mem {
   int channels = 1;
   int elem_kind = CLWH_ELEM_U8;
   int flags = 0;
-  uint64_t version = 0;
+  std::shared_ptr<clvr::VersionCell> cell;  // shared with every other clwh_mem of the same device pointer
+  uint64_t version() const { return cell ? cell->v.load(std::memory_order_relaxed) : 0; }
 };
+
+// a new content version for the object's device memory (seen through every clwh_mem that names the same pointer)
+void clwh_touch(clwh_mem *m);
 
 enum clwh_kernel_id {
   CLWH_K_EMPTY = 0,

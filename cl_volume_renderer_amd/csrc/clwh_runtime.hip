@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -21,8 +22,41 @@ static thread_local int g_last_hip_error = 0;
 
 // Content versions are drawn from one process-wide counter, so (device pointer, version) identifies a
 // content uniquely even when an object is released and another one is allocated at the same address.
+// The version lives in a cell shared by every clwh_mem of the same device pointer (the owner and its wraps in
+// other contexts): whoever rewrites the memory -- a push, clwh_sdf_build, clwh_mem_mark_dirty -- is seen by all of
+// them, so no context keeps rendering from derived data of the old content.
 static std::atomic<uint64_t> g_content_version{0};
-static inline void touch(clwh_mem *m) { m->version = ++g_content_version; }
+static std::mutex g_registry_mutex;  // guards the two process-wide registries below (contexts may live on different host threads)
+static std::map<const void *, std::weak_ptr<VersionCell>> g_version_cells;
+void clwh_touch(clwh_mem *m) { m->cell->v.store(++g_content_version, std::memory_order_relaxed); }
+static inline void touch(clwh_mem *m) { clwh_touch(m); }
+
+static std::shared_ptr<VersionCell> version_cell_of(const void *dptr) {
+  std::lock_guard<std::mutex> lock(g_registry_mutex);
+  auto it = g_version_cells.find(dptr);
+  if (it != g_version_cells.end())
+    if (auto live = it->second.lock()) return live;
+  auto cell = std::make_shared<VersionCell>();
+  g_version_cells[dptr] = cell;
+  if (g_version_cells.size() > 4096) {  // forget the cells nobody holds any more
+    for (auto i = g_version_cells.begin(); i != g_version_cells.end();)
+      i = i->second.expired() ? g_version_cells.erase(i) : std::next(i);
+  }
+  return cell;
+}
+
+// ---- the per-device registry of derived scene data (PackedScene, clwh_internal.hpp)
+static std::vector<std::weak_ptr<PackedScene>> g_packed_scenes;
+static std::atomic<uint64_t> g_packed_generation{0};
+
+PackedScene::~PackedScene() {
+  // the last context let go; another context that dropped its reference earlier may still have kernels in flight on its
+  // own stream that read this memory
+  (void)hipSetDevice(device);
+  (void)hipDeviceSynchronize();
+  if (data) (void)hipFree(data);
+  if (ready) (void)hipEventDestroy(ready);
+}
 
 #define HIP_TRY(expr)                                   \
   do {                                                  \
@@ -86,7 +120,7 @@ static int jit_for_source(clwh_ctx *ctx, const char *source, std::shared_ptr<Jit
 // class byte per voxel + colour palette of an opaque TF for `volume`; cached per (volume content, source)
 static int ensure_classes(clwh_ctx *ctx, const std::shared_ptr<JitTf> &jit, const clwh_mem *volume, TfDev &tf_out,
                           const uint8_t **cls_out) {
-  if (ctx->jit_cls && ctx->jit_vol == volume->dptr && ctx->jit_vol_ver == volume->version && ctx->jit_source == jit->source) {
+  if (ctx->jit_cls && ctx->jit_vol == volume->dptr && ctx->jit_vol_ver == volume->version() && ctx->jit_source == jit->source) {
     tf_out = ctx->jit_tf;
     *cls_out = ctx->jit_cls;
     return CLWH_OK;
@@ -135,7 +169,7 @@ static int ensure_classes(clwh_ctx *ctx, const std::shared_ptr<JitTf> &jit, cons
   t.border_class = (int32_t)(host[kColors + 1] & 0xFFull);  // is_event_gen(0, 0): the border texel (TfDev::border_class)
   ctx->jit_tf = t;
   ctx->jit_vol = volume->dptr;
-  ctx->jit_vol_ver = volume->version;
+  ctx->jit_vol_ver = volume->version();
   ctx->jit_source = jit->source;
   tf_out = t;
   *cls_out = ctx->jit_cls;
@@ -215,7 +249,9 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
   if (ctx->sdf_counters) (void)hipFree(ctx->sdf_counters);
   if (ctx->sdf_flags) (void)hipFree(ctx->sdf_flags);
   if (ctx->sdf_bits) (void)hipFree(ctx->sdf_bits);
-  if (ctx->packed) (void)hipFree(ctx->packed);
+  ctx->scene.reset();
+  if (ctx->host_n_hits) (void)hipHostFree(ctx->host_n_hits);
+  if (ctx->n_hits_event) (void)hipEventDestroy(ctx->n_hits_event);
   if (ctx->handoff_event) (void)hipEventDestroy(ctx->handoff_event);
   for (hipEvent_t e : ctx->ev_begin) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_end) (void)hipEventDestroy(e);
@@ -335,6 +371,9 @@ static int mem_new(clwh_ctx *ctx, void *dptr, size_t bytes, bool owned, clwh_mem
   m->dptr = dptr;
   m->bytes = bytes;
   m->owned = owned;
+  m->cell = version_cell_of(dptr);
+  // a new version also for a wrap of memory another clwh_mem already names: the caller may have rewritten it since, and
+  // the address may have been reused by its allocator -- the owner's derived data is rebuilt once per wrap
   touch(m);
   *out = m;
   return CLWH_OK;
@@ -526,43 +565,82 @@ static bool is_image(const clwh_mem *m, int dims_n, int channels, int elem_kind)
   return true;
 }
 
-// (re)build the bricked step bytes + hit records (packed_volume.hpp) when the volume, the SDF or the TF changed
-static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *sdf, const TfDev &tf, const uint8_t *cls_in) {
-  const int X = (int)volume->dims[0], Y = (int)volume->dims[1], Z = (int)volume->dims[2];
-  const int NBX = (X + 7) / 8, NBY = (Y + 7) / 8, NBZ = (Z + 7) / 8;
-  const size_t records = (size_t)NBX * NBY * NBZ * 512u;
-  const size_t n_bricks = (size_t)NBX * NBY * NBZ;
-  const int mshift = macro_cell_shift(X, Y, Z, ctx->tune_macro_shift), mcell = 1 << mshift;  // macro cells of the exit certificates
-  const int MNX = (X + mcell - 1) >> mshift, MNY = (Y + mcell - 1) >> mshift, MNZ = (Z + mcell - 1) >> mshift;
+// layout of a PackedScene's allocation
+struct PackedLayout {
+  int X, Y, Z, NBX, NBY, NBZ, mshift, MNX, MNY, MNZ;
+  size_t records, n_bricks, off_stepb, off_brick_min, off_macro, bytes;
+};
+static PackedLayout packed_layout(const clwh_mem *volume, int forced_macro_shift) {
+  PackedLayout L;
+  L.X = (int)volume->dims[0]; L.Y = (int)volume->dims[1]; L.Z = (int)volume->dims[2];
+  L.NBX = (L.X + 7) / 8; L.NBY = (L.Y + 7) / 8; L.NBZ = (L.Z + 7) / 8;
+  L.records = (size_t)L.NBX * L.NBY * L.NBZ * 512u;
+  L.n_bricks = (size_t)L.NBX * L.NBY * L.NBZ;
+  L.mshift = macro_cell_shift(L.X, L.Y, L.Z, forced_macro_shift);  // macro cells of the exit certificates
+  const int mcell = 1 << L.mshift;
+  L.MNX = (L.X + mcell - 1) >> L.mshift; L.MNY = (L.Y + mcell - 1) >> L.mshift; L.MNZ = (L.Z + mcell - 1) >> L.mshift;
   // hit records, the per-step bytes, the per-brick minima (u32, 16-byte aligned), the macro-cell table
-  const size_t off_brick_min = (records * (sizeof(uint2) + 1u) + 15u) & ~(size_t)15u;
-  const size_t off_macro = (off_brick_min + n_bricks * sizeof(uint32_t) + 15u) & ~(size_t)15u;
-  const size_t bytes = off_macro + (size_t)MNX * MNY * MNZ * 8u;  // eight octant entries per cell
-  if (ctx->packed_valid && ctx->packed_bytes == bytes && ctx->packed_vol == volume->dptr &&
-      ctx->packed_sdf == sdf->dptr && ctx->packed_vol_ver == volume->version &&
-      ctx->packed_sdf_ver == sdf->version && !std::memcmp(&ctx->packed_tf, &tf, sizeof tf))
-    return CLWH_OK;
-  ctx->packed_valid = false;
-  if (ctx->packed_bytes != bytes) {
-    if (ctx->packed) {
-      HIP_TRY(hipStreamSynchronize(ctx->stream));
-      HIP_TRY(hipFree(ctx->packed));
-      ctx->packed = nullptr;
-      ctx->packed_bytes = 0;
+  L.off_stepb = L.records * sizeof(uint2);
+  L.off_brick_min = (L.records * (sizeof(uint2) + 1u) + 15u) & ~(size_t)15u;
+  L.off_macro = (L.off_brick_min + L.n_bricks * sizeof(uint32_t) + 15u) & ~(size_t)15u;
+  L.bytes = L.off_macro + (size_t)L.MNX * L.MNY * L.MNZ * 8u;  // eight octant entries per cell
+  return L;
+}
+
+static bool packed_matches(const PackedScene &p, int device, const PackedLayout &L, const clwh_mem *volume, const clwh_mem *sdf,
+                           const TfDev &tf, const std::string &tf_identity) {
+  return !p.stale && p.device == device && p.bytes == L.bytes && p.macro_shift == L.mshift && p.vol == volume->dptr &&
+         p.sdf == sdf->dptr && p.vol_ver == volume->version() && p.sdf_ver == sdf->version() &&
+         !std::memcmp(&p.tf, &tf, sizeof tf) && p.tf_identity == tf_identity;
+}
+
+// the bricked step bytes + hit records (packed_volume.hpp) of (volume, SDF, TF): the context's own entry if it still matches,
+// else the entry another context of this device has built (its stream's work is ordered behind the build by an event), else
+// built here on the context's stream
+static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *sdf, const TfDev &tf, const uint8_t *cls_in,
+                         const std::string &tf_identity) {
+  const PackedLayout L = packed_layout(volume, ctx->tune_macro_shift);
+  if (ctx->scene && packed_matches(*ctx->scene, ctx->device, L, volume, sdf, tf, tf_identity)) return CLWH_OK;
+  std::shared_ptr<PackedScene> entry;
+  {
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    for (auto it = g_packed_scenes.begin(); it != g_packed_scenes.end();) {
+      std::shared_ptr<PackedScene> live = it->lock();
+      if (!live) { it = g_packed_scenes.erase(it); continue; }
+      if (!entry && packed_matches(*live, ctx->device, L, volume, sdf, tf, tf_identity)) entry = live;
+      ++it;
     }
-    HIP_TRY(hipMalloc((void **)&ctx->packed, bytes));
-    ctx->packed_bytes = bytes;
   }
+  if (entry) {
+    ctx->scene.reset();  // (frees the old entry if this context was its last holder)
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, entry->ready, 0));
+    ctx->scene = entry;
+    return CLWH_OK;
+  }
+  // build.  A context that is the only holder of an entry of the right size rebuilds in place (a transfer-function flush
+  // does not free and allocate 9 bytes per voxel); the stream orders the rebuild behind the kernels that still read it.
+  if (ctx->scene && ctx->scene.use_count() == 1 && ctx->scene->bytes == L.bytes) {
+    entry = ctx->scene;
+  } else {
+    ctx->scene.reset();
+    entry = std::make_shared<PackedScene>();
+    entry->device = ctx->device;
+    HIP_TRY(hipMalloc((void **)&entry->data, L.bytes));
+    entry->bytes = L.bytes;
+    HIP_TRY(hipEventCreateWithFlags(&entry->ready, hipEventDisableTiming));
+  }
+  ctx->scene.reset();
+  entry->stale = true;  // not adoptable until described below
   RepackArgs r;
   std::memset(&r, 0, sizeof r);
   r.volume = (const int16_t *)volume->dptr;
   r.sdf = (const int8_t *)sdf->dptr;
-  r.X = X; r.Y = Y; r.Z = Z;
-  r.NBX = NBX; r.NBY = NBY; r.NBZ = NBZ;
-  r.grec = reinterpret_cast<uint2 *>(ctx->packed);
-  r.stepb = ctx->packed + records * sizeof(uint2);
-  r.brick_min = reinterpret_cast<uint32_t *>(ctx->packed + off_brick_min);
-  HIP_TRY(hipMemsetAsync(r.brick_min, 0xFF, n_bricks * sizeof(uint32_t), ctx->stream));
+  r.X = L.X; r.Y = L.Y; r.Z = L.Z;
+  r.NBX = L.NBX; r.NBY = L.NBY; r.NBZ = L.NBZ;
+  r.grec = reinterpret_cast<uint2 *>(entry->data);
+  r.stepb = entry->data + L.off_stepb;
+  r.brick_min = reinterpret_cast<uint32_t *>(entry->data + L.off_brick_min);
+  HIP_TRY(hipMemsetAsync(r.brick_min, 0xFF, L.n_bricks * sizeof(uint32_t), ctx->stream));
   r.cls_in = cls_in;
   r.tf = tf;
   {
@@ -570,17 +648,28 @@ static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *
     int trc = t.begin(ctx, CLWH_TIMER_REPACK);
     if (trc != CLWH_OK) return trc;
     HIP_TRY(launch_repack(r, ctx->stream));
-    HIP_TRY(launch_macro_table(r.brick_min, NBX, NBY, NBZ, ctx->packed + off_macro, X, Y, Z, mshift, ctx->stream));
+    HIP_TRY(launch_macro_table(r.brick_min, L.NBX, L.NBY, L.NBZ, entry->data + L.off_macro, L.X, L.Y, L.Z, L.mshift, ctx->stream));
     trc = t.end();
     if (trc != CLWH_OK) return trc;
   }
-  ctx->packed_vol = volume->dptr;
-  ctx->packed_sdf = sdf->dptr;
-  ctx->packed_vol_ver = volume->version;
-  ctx->packed_sdf_ver = sdf->version;
-  ctx->packed_tf = tf;
-  ctx->packed_valid = true;
-  ctx->packed_generation++;
+  HIP_TRY(hipEventRecord(entry->ready, ctx->stream));
+  ctx->scene = entry;
+  {
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    entry->vol = volume->dptr;
+    entry->sdf = sdf->dptr;
+    entry->vol_ver = volume->version();
+    entry->sdf_ver = sdf->version();
+    entry->tf = tf;
+    entry->tf_identity = tf_identity;
+    entry->macro_shift = L.mshift;
+    entry->generation = ++g_packed_generation;
+    entry->stale = false;
+    bool listed = false;
+    for (auto &w : g_packed_scenes)
+      if (w.lock() == entry) listed = true;
+    if (!listed) g_packed_scenes.push_back(entry);
+  }
   return CLWH_OK;
 }
 
@@ -700,21 +789,20 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   a.unit_queues = ctx->tune_unit_queues;
 
   HIP_TRY(hipSetDevice(ctx->device));
-  int rc = ensure_packed(ctx, d->volume, d->sdf, a.tf, cls_in);
+  int rc = ensure_packed(ctx, d->volume, d->sdf, a.tf, cls_in, k->jit ? k->jit->source : std::string());
   if (rc != CLWH_OK) return rc;
-  a.grec = reinterpret_cast<const uint2 *>(ctx->packed);
-  a.NBX = (a.X + 7) / 8;
-  a.NBY = (a.Y + 7) / 8;
-  a.stepb = ctx->packed + (size_t)a.NBX * a.NBY * ((a.Z + 7) / 8) * 512u * sizeof(uint2);
-  a.volume_lin = (const int16_t *)d->volume->dptr;
-  a.sdf_lin = (const int8_t *)d->sdf->dptr;
   {
-    const size_t records = (size_t)a.NBX * a.NBY * ((a.Z + 7) / 8) * 512u, n_bricks = records / 512u;
-    const size_t off_brick_min = (records * (sizeof(uint2) + 1u) + 15u) & ~(size_t)15u;
-    a.macro = ctx->packed + ((off_brick_min + n_bricks * sizeof(uint32_t) + 15u) & ~(size_t)15u);
-    a.macro_shift = macro_cell_shift(a.X, a.Y, a.Z, ctx->tune_macro_shift);
-    const int mcell = 1 << a.macro_shift;
-    a.MNX = (a.X + mcell - 1) >> a.macro_shift; a.MNY = (a.Y + mcell - 1) >> a.macro_shift; a.MNZ = (a.Z + mcell - 1) >> a.macro_shift;
+    const PackedLayout L = packed_layout(d->volume, ctx->tune_macro_shift);
+    const uint8_t *packed = ctx->scene->data;
+    a.grec = reinterpret_cast<const uint2 *>(packed);
+    a.NBX = L.NBX;
+    a.NBY = L.NBY;
+    a.stepb = packed + L.off_stepb;
+    a.volume_lin = (const int16_t *)d->volume->dptr;
+    a.sdf_lin = (const int8_t *)d->sdf->dptr;
+    a.macro = packed + L.off_macro;
+    a.macro_shift = L.mshift;
+    a.MNX = L.MNX; a.MNY = L.MNY; a.MNZ = L.MNZ;
     // An exit certificate proves "this march leaves the volume without a Hit"; a position with a coordinate == dimension or NaN
     // reads the border texel (value 0), so tables under which value 0 can be an event keep marching literally.
     bool zero_may_hit = a.tf.border_class != 0;
@@ -752,9 +840,9 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   key.cache_entries = a.cache_entries;
   key.mode = a.mode;
   key.shading = a.shading;
-  key.packed_generation = ctx->packed_generation;
+  key.packed_generation = ctx->scene->generation;
   key.env = d->env->dptr;
-  key.env_version = d->env->version;
+  key.env_version = d->env->version();
   key.env_w = a.env_w; key.env_h = a.env_h;
   if (!ctx->primary_valid || std::memcmp(&key, &ctx->primary_key, sizeof key) != 0 || a.hit_index_out) {
     ctx->primary_valid = false;
@@ -765,25 +853,40 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     HIP_TRY(launch_primary(a, ctx->stream));
     rc = t.end();
     if (rc != CLWH_OK) return rc;
+    // the camera's hit count follows on the stream into page-locked memory; nobody waits for it
+    if (!ctx->host_n_hits) {
+      HIP_TRY(hipHostMalloc((void **)&ctx->host_n_hits, 64, hipHostMallocDefault));
+      HIP_TRY(hipEventCreateWithFlags(&ctx->n_hits_event, hipEventDisableTiming));
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->host_n_hits, ctx->render_counters, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->n_hits_event, ctx->stream));
+    ctx->n_hits_in_flight = true;
     ctx->primary_n_hits_known = false;
     ctx->primary_key = key;
     ctx->primary_valid = true;
   }
-  // The hit count stays on the device for single-pass launches (the reference's call pattern, one pass per
-  // renderer::render_frame): the bounce grid is then sized from the pixel count and the kernels read the count
-  // themselves, so a frame after a camera move costs no host round trip.  Multi-pass launches size their work
-  // buffers and scheduling thresholds from the real count: one 4-byte readback per camera.
-  const bool ao = d->shading == CLWH_SHADE_AO;
-  const bool count_on_device = a.n_seeds == 1 || ao;
-  if (!count_on_device && !ctx->primary_n_hits_known) {
-    uint32_t n_hits = 0;
-    HIP_TRY(hipMemcpyAsync(&n_hits, ctx->render_counters, sizeof n_hits, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->primary_n_hits = n_hits;
-    ctx->primary_n_hits_known = true;
+  // No host round trip per camera (the reference's queue is one in-order queue without a readback between camera and pass,
+  // app/renderer.cpp:145-150).  The kernels read the hit count from counters[0] themselves; the host only needs a bound of it
+  // for grid and buffer sizes, and uses the real count as soon as the copy above has arrived by itself.
+  if (ctx->n_hits_in_flight && !ctx->primary_n_hits_known) {
+    if (hipEventQuery(ctx->n_hits_event) == hipSuccess) {
+      ctx->primary_n_hits = *ctx->host_n_hits;
+      ctx->primary_n_hits_known = true;
+      ctx->n_hits_in_flight = false;
+      ctx->last_known_n_hits = ctx->primary_n_hits;
+    } else {
+      (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure: keep it out of the launches' error checks
+    }
   }
-  a.n_hits_on_device = count_on_device && !ctx->primary_n_hits_known;
+  const bool ao = d->shading == CLWH_SHADE_AO;
+  a.n_hits_on_device = !ctx->primary_n_hits_known;
   a.n_hits = ctx->primary_n_hits_known ? ctx->primary_n_hits : (uint32_t)std::min<size_t>(slots, 0xFFFFFFFFu);  // else: upper bound
+  // what the count is LIKELY to be, for the scheduling class of the launch and the size of the fix-up buffer: the count itself, else
+  // twice the last camera's (a camera move rarely doubles the hit pixels), never below a quarter of the pixels
+  uint32_t n_hits_est = a.n_hits;
+  if (!ctx->primary_n_hits_known && ctx->last_known_n_hits != 0)
+    n_hits_est = (uint32_t)std::min<uint64_t>(a.n_hits, std::max<uint64_t>(2ull * ctx->last_known_n_hits, slots / 4u));
+  a.n_hits_estimate = n_hits_est;
   // the bounce kernel's queue arithmetic needs ceil(hits / 64) x seeds below 2^24 (64 seeds: 16.7 M hit pixels)
   if ((uint64_t)(((a.n_hits + 63u) >> 6) + 8u * (1u << ctx->tune_unit_block_log2)) * (uint64_t)a.n_seeds >= (1ull << 24)) return CLWH_ERR_INVALID_VALUE;
 
@@ -802,18 +905,22 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     if (rc != CLWH_OK) return rc;
   } else {
     // ---- the pass: every (hit, seed) item
-    // fix-up records for environment lookups the fast path cannot certify: room for 1/16 of the items;
-    // the expected rate is 4e-6 x (0.16 w + 0.32 h) per lookup: 0.5 % at 4096x2048, 4 % at the 32768 limit
-    const size_t fix_cap = std::max<size_t>(((size_t)a.n_hits * (size_t)a.n_seeds) / 16u, 4096u);
+    // fix-up records for environment lookups the fast path cannot certify.  Expected rate: 4e-6 x (0.16 w + 0.32 h) per lookup, at
+    // most two lookups per item (0.5 % at 4096x2048, 4 % at the 32768 limit); room for three times that, never less than 1/64 of the
+    // items -- of the ESTIMATED item count while the camera's hit count is still on its way (an overflow is reported, not silent)
+    const double rate = std::min(1.0, std::max(1.0 / 64.0, 3.0 * 8.0e-6 * (0.16 * a.env_w + 0.32 * a.env_h)));
+    const size_t fix_cap = std::max<size_t>((size_t)((double)n_hits_est * (double)a.n_seeds * rate), 4096u);
     rc = grow(ctx, (void **)&ctx->fixups, &ctx->fixups_bytes, fix_cap * 128u);
     if (rc != CLWH_OK) return rc;
     a.fixups = ctx->fixups;
     a.fixup_capacity = (uint32_t)std::min<size_t>(ctx->fixups_bytes / 128u, 0x7fffffffu);
     if (a.mode == CLWH_ACCUM_IMAGE_SPACE) {
-      rc = grow(ctx, (void **)&ctx->delta, &ctx->delta_bytes, std::max<size_t>(a.n_hits, 1) * sizeof(unsigned long long));
+      // one 64-bit delta per hit; k_commit folds a launch's deltas into the accumulator and leaves them zero for the next launch
+      const size_t before = ctx->delta_bytes;
+      rc = grow(ctx, (void **)&ctx->delta, &ctx->delta_bytes, std::max<size_t>(slots, 1) * sizeof(unsigned long long));
       if (rc != CLWH_OK) return rc;
       a.delta = ctx->delta;
-      HIP_TRY(hipMemsetAsync(ctx->delta, 0, (size_t)a.n_hits * sizeof(unsigned long long), ctx->stream));
+      if (ctx->delta_bytes != before) HIP_TRY(hipMemsetAsync(ctx->delta, 0, ctx->delta_bytes, ctx->stream));
     }
     TimedLaunch t;
     rc = t.begin(ctx, CLWH_TIMER_BOUNCE);
@@ -927,8 +1034,25 @@ int clwh_frame_from_tiles(clwh_ctx *ctx, clwh_mem *tiles_all, int32_t tile_world
 
 int clwh_ctx_invalidate_derived(clwh_ctx *ctx, int what) {
   if (!ctx) return CLWH_ERR_INVALID_VALUE;
-  if (what & CLWH_DERIVED_SCENE) ctx->packed_valid = false;
+  if ((what & CLWH_DERIVED_SCENE) && ctx->scene) {
+    // this context rebuilds at its next render and nobody adopts the old copy any more; contexts that already share it keep it
+    // until their own key changes (memory rewritten behind the shim's back is what clwh_mem_mark_dirty is for: every alias sees it)
+    {
+      std::lock_guard<std::mutex> lock(g_registry_mutex);
+      ctx->scene->stale = true;
+    }
+    if (ctx->scene.use_count() > 1) ctx->scene.reset();  // the only holder keeps the allocation and rebuilds in place
+  }
   if (what & (CLWH_DERIVED_SCENE | CLWH_DERIVED_CAMERA)) ctx->primary_valid = false;
+  return CLWH_OK;
+}
+
+int clwh_ctx_scene_info(clwh_ctx *ctx, uint64_t *scene_id, uint64_t *bytes, int32_t *holders) {
+  if (!ctx) return CLWH_ERR_INVALID_VALUE;
+  std::lock_guard<std::mutex> lock(g_registry_mutex);
+  if (scene_id) *scene_id = ctx->scene ? ctx->scene->generation : 0;
+  if (bytes) *bytes = ctx->scene ? ctx->scene->bytes : 0;
+  if (holders) *holders = ctx->scene ? (int32_t)ctx->scene.use_count() : 0;
   return CLWH_OK;
 }
 

@@ -380,6 +380,7 @@ __global__ __launch_bounds__(256) void k_commit(const RenderArgs a) {
   if (h >= (a.n_hits_on_device ? a.counters[0] : a.n_hits)) return;
   const unsigned long long d = a.delta[h];
   if (d == 0ull) return;
+  a.delta[h] = 0ull;  // ready for the next launch: the host never clears the deltas (it does not know how many there are)
   const uint32_t pslot = a.hits[h].pslot;
   float4 acc = a.accum[pslot];
   // integer-valued floats below 2^24: exact
@@ -416,8 +417,14 @@ __device__ __forceinline__ bool certify_exit(const RenderArgs &a, f3 p, f3 d, in
                  cz = min((unsigned)(int)p.z >> a.macro_shift, (unsigned)a.MNZ - 1u);
   const unsigned octant = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
   const int bound = a.macro[((((size_t)cz * (size_t)a.MNY + (size_t)cy) * (size_t)a.MNX + (size_t)cx) << 3) | octant];
+  // The bound counts steps of at least the box's smallest SDF value.  One kind of position is outside that reasoning: a
+  // coordinate that landed exactly ON the far face (== dimension: not exited, utility_ray.cl:112-117) reads the border SDF 0 and
+  // advances 0.5 |d| per step; with a direction component too small to move that coordinate (0.5 x 2^-10 is above half an ulp of
+  // every dimension below 2^13) the reference can crawl along the face and even run out of its 70 steps.  Such directions get
+  // no certificate and march literally; for all others the next step leaves, which the bound's + 5 covers.
+  const float dmin = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
   const float dsum = d.x + d.y + d.z;  // NaN direction: the position turns NaN and never leaves
-  return bound <= budget && dsum == dsum;
+  return bound <= budget && dmin >= 0.0009765625f && dsum == dsum;
 }
 
 #ifndef CLVR_BOUNCE_WAVES_PER_SIMD
@@ -1038,8 +1045,10 @@ hipError_t launch_bounce(const RenderArgs &a_in, hipStream_t s) {
   // A long launch is bound by VALU issue: lanes refill at 16 idle and the march phase ends at 16 marching lanes.
   // Measured crossover on the headline scene: between 4 and 8 passes per launch = about 6 units per wave
   // (profiles/r01_tune_refill_step_thresholds.txt).
-  // (with the hit count still on the device n_hits is the pixel count, an upper bound: such launches are single-pass)
-  const bool long_launch = a.force_long_launch || (!a.n_hits_on_device && waves_needed >= 6u * (uint64_t)blocks * wpb);
+  // (with the hit count still on the device n_hits is the pixel count, an upper bound; the class follows the estimate: the last
+  // camera's count with slack, clwh_render)
+  const uint64_t waves_likely = ((uint64_t)a.n_hits_estimate * (uint64_t)a.n_seeds + 63u) / 64u;
+  const bool long_launch = a.force_long_launch || waves_likely >= 6u * (uint64_t)blocks * wpb;
   if (a.step_min_lanes <= 0) a.step_min_lanes = long_launch ? 16 : 1;
   if (a.refill_min_lanes <= 0) a.refill_min_lanes = long_launch ? 16 : 64;
   // certificates: a long launch looks them up once 16 lanes of a wave wait for one (8: 4.32, 16: 4.25, 4: 4.42 ms); a short launch

@@ -108,8 +108,12 @@ _PROTOTYPES = [
                                            C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("clwh_frame_from_tiles", C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("clwh_ctx_invalidate_derived", C.c_int, [C.c_void_p, C.c_int]),
+    ("clwh_ctx_scene_info", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
     ("clwh_sdf_build", C.c_int, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int32)]),
     ("clwh_buffer_reset", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("clwh_cache_exchange_plan", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    ("clwh_cache_apply_contributions", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    ("clwh_cache_exchange_plan_release", C.c_int, [C.c_void_p]),
     ("clwh_tf_parse", C.c_int, [C.c_char_p, C.POINTER(Tf)]),
     ("clwh_strerror", C.c_char_p, [C.c_int]),
     ("clwh_last_hip_error", C.c_int, []),
@@ -237,6 +241,21 @@ class Kernel:
             self.h = None
 
 
+class ExchangePlan:
+    def __init__(self, ctx, handle):
+        self.ctx, self.h = ctx, C.c_void_p(handle)
+
+    def apply(self, buffer_volume: Mem, rgb: Mem, rgb_stride=3):
+        """one pass's contributions (int32[n][rgb_stride], the plan's order) into the cache under the 256-token rule"""
+        _check(lib().clwh_cache_apply_contributions(self.ctx.h, self.h, buffer_volume.h, rgb.h, rgb_stride),
+               "clwh_cache_apply_contributions")
+
+    def release(self):
+        if self.h:
+            _check(lib().clwh_cache_exchange_plan_release(self.h), "clwh_cache_exchange_plan_release")
+            self.h = None
+
+
 class Context:
     def __init__(self, device=0, stream=None):
         h = C.c_void_p()
@@ -298,6 +317,12 @@ class Context:
     def buffer_reset(self, buffer_volume: Mem):
         _check(lib().clwh_buffer_reset(self.h, buffer_volume.h), "clwh_buffer_reset")
 
+    def exchange_plan(self, entries: Mem, n: int) -> "ExchangePlan":
+        """group the listed cache entries (int64[n], (rank, pixel) order) by voxel: once per camera"""
+        h = C.c_void_p()
+        _check(lib().clwh_cache_exchange_plan(self.h, entries.h, int(n), C.byref(h)), "clwh_cache_exchange_plan")
+        return ExchangePlan(self, h.value)
+
     def accum_resolve(self, accum_all: Mem, tile_world, width, height, frame: Mem, env: Mem, cam_pos, cam_dir):
         p = (C.c_float * 3)(*[float(x) for x in cam_pos])
         d = (C.c_float * 3)(*[float(x) for x in cam_dir])
@@ -317,6 +342,12 @@ class Context:
     def invalidate_derived(self, scene=True, camera=True):
         what = (DERIVED_SCENE if scene else 0) | (DERIVED_CAMERA if camera else 0)
         _check(lib().clwh_ctx_invalidate_derived(self.h, what), "clwh_ctx_invalidate_derived")
+
+    def scene_info(self):
+        """(id, bytes, holders) of the derived scene data this context renders from"""
+        sid, nb, holders = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
+        _check(lib().clwh_ctx_scene_info(self.h, C.byref(sid), C.byref(nb), C.byref(holders)), "clwh_ctx_scene_info")
+        return int(sid.value), int(nb.value), int(holders.value)
 
     def image_wrap(self, device_ptr: int, dims, channels, dtype, shape=None) -> Mem:
         """adopt device memory somebody else allocated (a graphics-interop mapping, a torch tensor) as an image"""

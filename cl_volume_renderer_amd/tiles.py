@@ -125,18 +125,29 @@ class VoxelExchange:
     deterministic rule: the contributions to one voxel are taken in (rank, pixel) order while the voxel's count is
     below 256 and dropped afterwards.  That is one legal outcome of the reference's race (which of the competing
     work-items gets the last tokens is unspecified there), identical on every rank, identical to the single-GPU
-    cache while the global count stays below the cap, and never above the cap.  torch ops only: runs on the GPUs
-    over RCCL and on CPU tensors over gloo (tests/test_multi_rank_cpu.py)."""
+    cache while the global count stays below the cap, and never above the cap.
+
+    On the GPU the grouping and the capped add are the library's (`clwh_cache_exchange_plan`, one stable sort per camera;
+    `clwh_cache_apply_contributions`, ONE kernel per pass -- the entry points a C/C++ caller uses as well); this class
+    only adds the two all-gathers.  `ctx`: the ffi.Context whose stream the collectives' results are consumed on; a
+    device cache without one is refused.  The torch restatement of the same rule below is for CPU tensors over gloo
+    (tests/test_multi_rank_cpu.py), where no GPU exists."""
 
     CAP = 256
 
-    def __init__(self, cache_words, world: int):
+    def __init__(self, cache_words, world: int, ctx=None):
         import torch
 
         self.torch = torch
         self.words = cache_words        # 1-D int32 tensor, 2 words per entry: r | g << 16, b | count << 16
         self.world = world
         self.dev = cache_words.device
+        self.ctx = ctx
+        self.plan = None
+        if cache_words.is_cuda:
+            if ctx is None:
+                raise RuntimeError("VoxelExchange on device memory needs the ffi.Context of the HIP library (no torch fallback on the GPU)")
+            self.m_cache = ctx.wrap(cache_words.data_ptr(), cache_words.numel() * 4)
 
     def _all_gather_padded(self, t, n_max):
         """ranks contribute tensors whose first dimension differs: pad to n_max rows, gather, return the list"""
@@ -177,6 +188,18 @@ class VoxelExchange:
         self.n_max = max(max(self.sizes), 1)
         parts = self._all_gather_padded(own_entries, self.n_max)
         entries = torch.cat([p[:n] for p, n in zip(parts, self.sizes)])     # (rank, pixel) order
+        if self.ctx is not None:
+            if self.plan is not None:
+                self.plan.release()
+            self.plan = None
+            self.entries = entries.contiguous()
+            if self.entries.numel() == 0:   # no rank hit anything: nothing to exchange for this camera
+                return
+            torch.cuda.current_stream().synchronize()  # the plan is built on the context's stream
+            m_entries = self.ctx.wrap(self.entries.data_ptr(), self.entries.numel() * 8)
+            self.plan = self.ctx.exchange_plan(m_entries, self.entries.numel())   # blocking: the list is consumed here
+            m_entries.release()
+            return
         # group the contributions by voxel, keeping (rank, pixel) order inside a group
         order = torch.argsort(entries, stable=True)
         sorted_e = entries[order]
@@ -190,6 +213,15 @@ class VoxelExchange:
         entries given to set_camera).  One all-gather, then the capped scatter-add into the replica."""
         torch = self.torch
         parts = self._all_gather_padded(own_rgb, self.n_max)
+        if self.ctx is not None:
+            if self.plan is None:
+                return
+            rgb = parts[0][: self.sizes[0]] if self.world == 1 else torch.cat([p[:n] for p, n in zip(parts, self.sizes)])
+            self.rgb = rgb.to(torch.int32).contiguous()   # kept alive until the next pass: the kernel reads it asynchronously
+            m_rgb = self.ctx.wrap(self.rgb.data_ptr(), self.rgb.numel() * 4)
+            self.plan.apply(self.m_cache, m_rgb, int(self.rgb.shape[1]))
+            m_rgb.release()
+            return
         rgb = torch.cat([p[:n] for p, n in zip(parts, self.sizes)])[self.order].to(torch.int64)
         u = self.unique
         w0 = self.words[2 * u].to(torch.int64) & 0xFFFFFFFF

@@ -67,8 +67,10 @@ int clwh_ctx_device(clwh_ctx *ctx);
  * clwh_mem_create    replaces clCreateBuffer in clw_vector's ctor (clw_vector.hpp:14-33)
  * clwh_image_create  replaces clCreateImage in clw_image's ctor  (clw_image.hpp:18-137);
  *                    dims of 0 count as 1; 1-D/2-D/3-D follows from the dims
- * clwh_mem_wrap      adopts device memory the caller allocated (a torch tensor's data_ptr);
- *                    never freed by the shim
+ * clwh_mem_wrap      adopts device memory the caller allocated (a torch tensor's data_ptr) or that another
+ *                    clwh_mem -- of this or another context -- already names; never freed by the shim.  All objects
+ *                    that name the same device pointer share ONE content version: a push, clwh_sdf_build or
+ *                    clwh_mem_mark_dirty through any of them invalidates what every context derived from it
  * clwh_mem_push/pull replace the blocking clEnqueueWrite/Read{Buffer,Image}
  *                    (clw_vector.hpp:73-86, clw_image.hpp:202-216); `bytes` must equal the object size
  */
@@ -199,12 +201,20 @@ int clwh_accum_resolve_tiles(clwh_ctx *ctx, clwh_mem *accum, int32_t tile_rank, 
                              const float cam_dir[3]);
 int clwh_frame_from_tiles(clwh_ctx *ctx, clwh_mem *tiles_all_ranks, int32_t tile_world, uint32_t width, uint32_t height,
                           clwh_mem *frame_rgba8);
-/* drop what the context derived from its inputs; the next clwh_render rebuilds it.  Needed only when
- * device memory was rewritten behind the shim's back, or to time the rebuild.
- *   CLWH_DERIVED_SCENE   step bytes + hit records (function of volume, SDF, transfer function: flush-time data)
- *   CLWH_DERIVED_CAMERA  primary hits (function of the camera and of the scene) */
+/* drop what the context derived from its inputs; the next clwh_render rebuilds it.  Needed only to time the
+ * rebuild or to render "the first frame after a camera move" again (memory rewritten behind the shim's back
+ * is what clwh_mem_mark_dirty is for).
+ *   CLWH_DERIVED_SCENE   step bytes + hit records + exit-certificate table (function of volume, SDF, transfer
+ *                        function: flush-time data).  There is ONE copy per device: contexts that render the same
+ *                        (volume content, SDF content, transfer function) share it -- 9 bytes per voxel, 72 GiB at
+ *                        2048^3 -- and it is freed when the last of them lets go.  Invalidating makes THIS context
+ *                        rebuild; contexts already sharing the old copy keep it until their own inputs change.
+ *   CLWH_DERIVED_CAMERA  primary hits (function of the camera and of the scene), per context */
 enum clwh_derived { CLWH_DERIVED_SCENE = 1, CLWH_DERIVED_CAMERA = 2 };
 int clwh_ctx_invalidate_derived(clwh_ctx *ctx, int what);
+/* which copy of the derived scene data the context renders from (after its last clwh_render): a process-wide unique id
+ * of the content (0: none yet), its size in bytes, and how many contexts hold it right now */
+int clwh_ctx_scene_info(clwh_ctx *ctx, uint64_t *scene_id, uint64_t *bytes, int32_t *holders);
 
 /* clwh_sdf_build replaces the host loop of signed_distance_field::signed_distance_field
  * (app/signed_distance_field.cpp:7-35): base image + all propagation layers, no host round trip
@@ -215,6 +225,26 @@ int clwh_sdf_build(clwh_ctx *ctx, clwh_mem *volume, const char *tf_source, clwh_
 
 /* buffer_reset.cl:3-13 / app/renderer.cpp:32-35 */
 int clwh_buffer_reset(clwh_ctx *ctx, clwh_mem *buffer_volume);
+
+/* ---- the reference's world-space accumulation fed with contributions computed elsewhere (the pixels of other
+ * ranks): utility.cl:20-54 (token + add) with the 256-token rule of ray_marching.cl:28,39 applied to the GLOBAL
+ * count ("reference-exact voxel-cache mode").  The reference hands a voxel's tokens to whichever
+ * work-items reach the atomic first; across GPUs the exchange fixes one legal outcome of that race instead: the
+ * contributions to a voxel are taken in the order the caller lists them -- (rank, pixel) -- while the voxel's count
+ * is below 256 and dropped afterwards, so every rank that applies the same list to its replica of buffer_volume ends
+ * with the same bytes, equal to the single-GPU cache while the count stays below the cap.
+ *   clwh_cache_exchange_plan         once per camera.  entries: int64[n] on the device, the cache entry (what
+ *                                    clwh_render_desc.hit_index reports) of every contributing pixel of every rank
+ *                                    in (rank, pixel) order; entries outside the cache are ignored.  Blocking
+ *                                    (one stable sort).
+ *   clwh_cache_apply_contributions   once per pass.  rgb: int32[n][rgb_stride] on the device, the pass's contribution
+ *                                    of each listed pixel (clwh_render_desc.contrib rows, gathered), same order.
+ *                                    One kernel on the context's stream, no host round trip. */
+typedef struct clwh_exchange_plan clwh_exchange_plan;
+int clwh_cache_exchange_plan(clwh_ctx *ctx, clwh_mem *entries, uint64_t n, clwh_exchange_plan **out);
+int clwh_cache_apply_contributions(clwh_ctx *ctx, clwh_exchange_plan *plan, clwh_mem *buffer_volume, clwh_mem *rgb,
+                                   int32_t rgb_stride);
+int clwh_cache_exchange_plan_release(clwh_exchange_plan *plan);
 
 /* ---- display hand-off without a host readback.
  * Replaces clw_foreign_memory::acquire / release (opencl_wrapper/include/clw_foreign_memory.hpp:40-46:

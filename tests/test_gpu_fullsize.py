@@ -109,6 +109,53 @@ def test_job_level_properties_without_the_oracle(full):
         assert np.array_equal(cache[:, :3].sum(axis=0), eight[:, :3].astype(np.int64).sum(axis=0))
 
 
+def frame_tolerance(frame_a, frame_b):
+    """how far two RGBA8 resolves of the same job are apart, over the pixels both show as hits (alpha 1)"""
+    hit = (frame_a[..., 3] == 1) & (frame_b[..., 3] == 1)
+    d = np.abs(frame_a[hit][:, :3].astype(np.int16) - frame_b[hit][:, :3].astype(np.int16)).max(axis=1)
+    return {"hit_pixels": int(hit.sum()), "max_abs_diff": int(d.max()), "mean_abs_diff": round(float(d.mean()), 3),
+            "within_1_lsb": round(float((d <= 1).mean()), 4), "within_4_lsb": round(float((d <= 4).mean()), 4),
+            "within_16_lsb": round(float((d <= 16).mean()), 4)}
+
+
+def test_headline_frame_against_the_reference_exact_frame(full):
+    """north_star: "output pixels match ... within a stated float tolerance".  The headline job accumulates in image space
+    (float4 per pixel, 64 samples of THAT pixel); the reference accumulates per VOXEL with a cap of 256 samples shared by all
+    the pixels that hit the voxel (utility.cl:20-54, ray_marching.cl:82-99).  Same scene, camera and 64 seeds, both resolved
+    to RGBA8: the two are different estimators of the same radiance, and this is how far apart they are (DESIGN.md 2 quotes the
+    numbers; bench.py reports them as `tolerance_vs_reference_exact`).  Also exact: both agree on WHICH pixels are hits and on
+    every miss pixel's colour."""
+    g, pos, d = full["g"], full["pos"], full["d"]
+    ctx = g.ctx
+    seeds = scene.glibc_rand(64)
+    ctx.buffer_reset(g.accum[0])
+    g.render(pos, d, None, mode=ffi.ACCUM_IMAGE_SPACE, seeds=seeds, debug=False, write_frame=True)
+    image_space = g.frame.pull().copy()
+    ctx.buffer_reset(g.cache)
+    for i, s in enumerate(seeds):                      # the reference's call pattern: one pass per launch, cap on
+        g.render(pos, d, s, debug=False, write_frame=(i == 63))
+    exact = g.frame.pull().copy()
+    cache = g.cache.pull().reshape(-1, 4)
+    assert cache[:, 3].max() == 256                    # the cap IS reached on this job (VERDICT r2: 44 013 voxels)
+    assert np.array_equal(image_space[..., 3], exact[..., 3])
+    miss = exact[..., 3] == 200
+    assert np.array_equal(image_space[miss], exact[miss])
+    t = frame_tolerance(image_space, exact)
+    print("tolerance image-space vs reference-exact, config 2, 64 spp:", t)
+    assert t["hit_pixels"] > 300000
+    # Monte-Carlo estimators with 64 (pixel) vs up to 256 (voxel, several pixels) samples: most pixels agree within a few
+    # LSB after the tone curve, none is wildly off
+    assert t["within_16_lsb"] > 0.5 and t["mean_abs_diff"] < 24.0
+    # the same comparison with both sides capped the same way is exact: fused voxel-cache launches in the cap regime keep
+    # exactly min(requests, 256) samples per voxel, like the one-pass launches
+    ctx.buffer_reset(g.cache)
+    g.render(pos, d, None, seeds=seeds, debug=False, write_frame=True)
+    fused = g.cache.pull().reshape(-1, 4)
+    assert np.array_equal(fused[:, 3], cache[:, 3])
+    below = cache[:, 3] < 256
+    assert np.array_equal(fused[below], cache[below])
+
+
 def test_half_grid_rank_share_equals_the_default_grid(full, gpu_ctx_half_grid):
     """bench.py runs a rank's share of a multi-rank frame job with k_bounce on half the persistent grid (a placement knob): the
     rank-0 share of a 2-rank split, 64 fused passes, must give the same image-space sums bit for bit -- and they must be the
@@ -230,6 +277,32 @@ def test_config3_gradient_tf_at_full_size(gpu_ctx, orc):
     assert np.array_equal(cache[hit_entries, 3], np.minimum(per_voxel * 256, 256))   # min(requests, 256) per voxel
     assert int((cache[:, 3] > 0).sum()) == hit_entries.size
     assert cache[:, :3].max() <= 256 * 255
+    # The same transfer function as free-form source (outside the rule grammar -> hiprtc classifier, csrc/tf_jit.cpp).  By design
+    # that route is not bit-exact for rules that read `gradient`: a position whose +-1 taps round across an integer uses its
+    # voxel's class where the rule table takes the reference's seven literal fetches.  Count how often it shows:
+    # per-sample contributions of whole passes, hiprtc path vs rule-table path.
+    free_form = ("inline bool is_event_gen(short value, short gradient, int4 *color){\n"
+                 "  int4 shade = {255,204,153,127};\n"
+                 "  if((value >= 500) && (value <= 1200) && (gradient > 100) && (gradient < 4000)) { *color = shade; return true; }\n"
+                 "  return false;\n}\n")
+    with pytest.raises(ffi.ClwhError):
+        ffi.parse_tf(free_form)
+    assert tuple(orc.parse_tf(tf).rules[0].color) == (255, 204, 153, 127)
+    gj = GpuScene(gpu_ctx, vol, None, env, free_form, (W, H))
+    gpu_ctx.sdf_build(gj.volume, free_form, gj.sdf)
+    assert np.array_equal(gj.sdf.pull(), sdf)
+    differing = samples = 0
+    gpu_ctx.buffer_reset(g.cache)
+    for s in seeds[:4]:
+        g.render(pos, d, s)
+        gj.render(pos, d, s)
+        a, b = g.contrib.pull(), gj.contrib.pull()
+        assert np.array_equal(g.hit_index.pull(), gj.hit_index.pull())
+        differing += int((a != b).any(axis=1).sum())
+        samples += int((a[:, 3] > 0).sum())
+    print("hiprtc vs rule table, gradient TF, config 3: %d of %d per-sample contributions differ" % (differing, samples))
+    assert samples > 1200000 and differing <= samples // 10000
+    gj.release()
     g.release()
 
 
@@ -310,8 +383,150 @@ def test_config4_2048_volume_on_one_gpu(gpu_ctx, orc):
     step = 1 << 28   # count_nonzero over the whole 64 GiB tensor would allocate a 128 GiB temporary
     touched_words = sum(int(torch.count_nonzero(cache[i:i + step]).item()) for i in range(0, cache.numel(), step))
     assert touched_words == int(np.count_nonzero(w0) + np.count_nonzero(w1))   # nothing else was touched
-    for mobj in (d_vol, d_sdf, d_env, d_frame, m_accum, m_hit, m_contrib):
+    del cache, o
+    torch.cuda.empty_cache()
+    for mobj in (m_accum, m_hit, m_contrib):
         mobj.release()
+
+    # ---- the launch bench.py --config 4 times: the 4K frame, 64 seeds fused into ONE image-space launch.  At 2048^3 the brick
+    # index is 64-bit (k_bounce<.., SMALL_VOLUME = false>), the launch is a LONG one (lanes refill early, exit certificates on a
+    # table of 64^3 cells) -- it must equal the same 64 seeds one per launch (short launches, no certificates) bit for bit, and
+    # two seeds must equal the oracle's image-space sums
+    w4, h4 = 3840, 2160
+    n_acc = ffi.accum_len(w4, h4, 1)
+    acc_fused = ctx.buffer(n_acc * 16, np.float32)
+    acc_single = ctx.buffer(n_acc * 16, np.float32)
+    ctx.buffer_reset(acc_fused)
+    ctx.buffer_reset(acc_single)
+    seeds = scene.glibc_rand(64)
+
+    def image_pass(acc, **kw):
+        k.render(frame=None, volume=d_vol, sdf=d_sdf, env=d_env, accum=acc, cam_pos=pos, cam_dir=d, seed=kw.pop("seed", 0),
+                 width=w4, height=h4, mode=ffi.ACCUM_IMAGE_SPACE, write_frame=False, **kw)
+
+    image_pass(acc_single, seed=seeds[0])    # first launch of this camera: the hit count becomes known to the host behind it
+    ctx.finish()
+    image_pass(acc_fused, seeds=seeds)       # 64 passes, one launch: 1.3 M hits x 64 = a long launch
+    for s in seeds[1:]:
+        image_pass(acc_single, seed=s)
+    ctx.finish()
+    fused = acc_fused.pull(np.float32).reshape(-1, 4)
+    assert set(np.unique(fused[:, 3])) == {0.0, 64.0} and int((fused[:, 3] > 0).sum()) > 1000000
+    assert np.array_equal(acc_single.pull(np.float32).reshape(-1, 4), fused)
+    ctx.buffer_reset(acc_single)
+    o4 = orc.Scene(vol, sdf, env, orc.parse_tf(tf), (w4, h4), mode=orc.MODE_IMAGE_SPACE, threads=threads)
+    for s in seeds[:2]:
+        image_pass(acc_single, seed=s)
+        o4.render(pos, d, s)
+    two = acc_single.pull(np.float32).reshape(h4 // 8, w4 // 8, 8, 8, 4).transpose(0, 2, 1, 3, 4).reshape(h4, w4, 4)
+    assert np.array_equal(two, o4.accum)
+    del o4, two, fused
+    acc_fused.release()
+    acc_single.release()
+
+    # ---- the kernels next to the path at 2048^3: more than 2^32 voxels, every index 64-bit
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import orc_volume
+
+    assert vol.size > 2 ** 32
+    ev = lambda g, l=8: (g + l - 1) // l * l  # noqa: E731
+    G = [ev(n), ev(n), ev(n)]
+    init = np.array([2**31 - 1, -2**31, 2**31 - 1, -2**31, -2**31], dtype=np.int32)
+    stats = ctx.buffer_from(init)
+    ks = ctx.kernel("reference_volume_figures.cl", "fetch_stats")
+    ks.launch(G, [4, 4, 4], d_vol, stats)
+    st = stats.pull()
+    W5 = H5 = 500
+    bins = ctx.buffer_from(np.zeros(W5 * H5, np.uint32))
+    kh = ctx.kernel("histogram.cl", "tf_sort_values")
+    kh.launch(G, [4, 4, 4], d_vol, bins, np.uint32(W5), np.uint32(H5), float(st[0]), float(st[1]), float(st[2]), float(st[3]))
+    got_bins = bins.pull().astype(np.int64)
+
+    def slab(z0):
+        """statistics and histogram of slices [z0, z0 + 16) with their neighbours (border texel 0 outside the volume)"""
+        z1 = min(z0 + 16, n)
+        lo, hi = max(z0 - 1, 0), min(z1 + 1, n)
+        part = vol[lo:hi]
+        g = orc_volume.gradient_length_f32(part)
+        # (gradient_length_f32 treats the first / last slice it is given as the volume's border: only the slices with both
+        # neighbours inside `part`, or really on the border, are kept)
+        a, b = z0 - lo, z0 - lo + (z1 - z0)
+        g, v = g[a:b], part[a:b]
+        gi = g.astype(np.int32)
+        f32 = np.float32
+        vf = v.astype(np.float32)
+        keep = ~(g > f32(st[3])) & ~(vf > f32(st[1]))
+        px = orc_volume._round_half_away(((vf - f32(st[0])) / (f32(st[1]) - f32(st[0]))) * f32(W5)).astype(np.int64)
+        py = orc_volume._round_half_away(((g - f32(st[2])) / (f32(st[3]) - f32(st[2]))) * f32(H5)).astype(np.int64)
+        keep &= (px >= 0) & (px < W5) & (py >= 0) & (py < H5)
+        hist = np.bincount((px[keep] * H5 + py[keep]).ravel(), minlength=W5 * H5)
+        return int(v.min()), int(v.max()), int(gi.min()), int(gi.max()), hist
+
+    # (statistics first: the histogram's ranges are the GPU's own statistics, checked right here against numpy)
+    def slab_stats(z0):
+        z1 = min(z0 + 16, n)
+        lo, hi = max(z0 - 1, 0), min(z1 + 1, n)
+        gi = orc_volume.gradient_length_int(vol[lo:hi])[z0 - lo:z0 - lo + (z1 - z0)]
+        v = vol[z0:z1]
+        return int(v.min()), int(v.max()), int(gi.min()), int(gi.max())
+
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        parts = list(pool.map(slab_stats, range(0, n, 16)))
+    want_stats = [min(p[0] for p in parts), max(p[1] for p in parts), min(p[2] for p in parts), max(p[3] for p in parts)]
+    assert st[:4].tolist() == want_stats and st[4] == init[4]
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        want_bins = sum(p[4] for p in pool.map(slab, range(0, n, 16)))
+    assert int(got_bins.sum()) > 2 ** 32 and np.array_equal(got_bins, want_bins)   # more counted voxels than 32 bits of indices
+    for mobj in (stats, bins):
+        mobj.release()
+    ks.release(); kh.release()
+
+    # apply_clip of a box whose source voxels lie beyond index 2^32
+    start, length = (900, 1000, 1990), (256, 128, 40)
+    dst = ctx.image(list(length), 1, np.int16, (length[2], length[1], length[0]))
+    b_start = ctx.buffer_from(np.array(start, np.uint32))
+    b_len = ctx.buffer_from(np.array(list(length) + [4], np.uint32))
+    kc = ctx.kernel("reference_volume_clip.cl", "apply_clip")
+    kc.launch(list(length), [4, 4, 4], d_vol, dst, b_start, b_len)
+    assert (start[2] * n + start[1]) * n + start[0] > 2 ** 32
+    assert np.array_equal(dst.pull(), orc_volume.apply_clip(vol, start, length))
+    for mobj in (dst, b_start, b_len):
+        mobj.release()
+    kc.release()
+
+    # the two generic SDF launches (the reference's own host loop, app/signed_distance_field.cpp:7-35) over 2^33 work-items: the base
+    # image and layer 1, whole volume, against the field clwh_sdf_build produced (its values 1 and 2 settle exactly there)
+    ping = ctx.image([n, n, n], 1, np.int8, (n, n, n))
+    pong = ctx.image([n, n, n], 1, np.int8, (n, n, n))
+    counter = ctx.buffer_from(np.zeros(1, np.int32))
+    kb = ctx.kernel("signed_distance_field.cl", "create_base_image", tf)
+    kl = ctx.kernel("signed_distance_field.cl", "create_signed_distance_field")
+    kb.launch(G, [4, 4, 4], d_vol, ping, pong, np.uint32(127))
+    h_ping, h_pong = ping.pull(), pong.pull()
+
+    def base_ok(z0):
+        f, sl = sdf[z0:z0 + 64], slice(z0, z0 + 64)
+        want = np.where(np.abs(f) == 1, f, np.where(f < 0, np.int8(-127), np.int8(127)))
+        return np.array_equal(h_ping[sl], want) and np.array_equal(h_pong[sl], want)
+
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        assert all(pool.map(base_ok, range(0, n, 64)))
+    kl.launch(G, [4, 4, 4], ping, pong, np.int32(1), counter, np.int32(127))
+    h_pong = pong.pull()
+
+    def layer_ok(z0):
+        f, sl = sdf[z0:z0 + 64], slice(z0, z0 + 64)
+        low = np.abs(f) <= 2
+        return np.array_equal(h_pong[sl], np.where(low, f, np.where(f < 0, np.int8(-127), np.int8(127)))), int(np.count_nonzero(low))
+
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        res = list(pool.map(layer_ok, range(0, n, 64)))
+    assert all(r[0] for r in res)
+    assert int(counter.pull()[0]) == sum(r[1] for r in res)     # written voxels: those holding 1 and those settling to 2
+    del h_ping, h_pong
+    for mobj in (ping, pong, counter, d_vol, d_sdf, d_env, d_frame):
+        mobj.release()
+    kb.release(); kl.release()
     k.release()
-    del cache
     torch.cuda.empty_cache()
