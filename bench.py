@@ -30,7 +30,16 @@ The JSON line also carries
                  workload (rank 0, N=1 only);
   end_to_end     the same jobs including the final blocking frame readback (SURVEY 8d metric ii);
   drop_in_path   renderer::render_frame x 64 through the C++ host mirror (one pass per launch + frame.pull(),
-                 the reference's own call pattern), and the readback-free / batched variants beside it.
+                 the reference's own call pattern), and the readback-free / batched variants beside it;
+  hit_samples_per_sec, frame_filling_view
+                 what the headline hides: 84 % of the default view's pixels miss the volume and cost nothing per pass.  The
+                 traced (hit pixel, pass) samples per second of the headline job, and the same job from a pose whose frame the
+                 volume fills (scene.close_camera: 78 % hit pixels) with its own value and k_bounce roofline;
+  reference_exact_mode
+                 the reference's own accumulation (world-space voxel cache, 256-token cap): one pass per launch and 64 passes
+                 fused into one launch;
+  tolerance_vs_reference_exact
+                 how far the headline's image-space frame is from the reference-exact frame of the same job (RGBA8, hit pixels).
 """
 from __future__ import annotations
 
@@ -136,6 +145,14 @@ def bytes_bounce(c):
     the rays that leave, one 8-byte atomic per granted sample"""
     return ((c["n_sdf"] - c["n_sdf_primary"]) + 2 * (c["n_vol"] - c["n_vol_primary"])
             + 4 * (c["n_env"] - c["n_env_primary"]) + 8 * c["n_add"])
+
+
+def bytes_bounce_executed(c):
+    """what k_bounce really fetches per pass, at texel granularity: ONE step byte per march step (the class bit and the next
+    step's SDF value share it), one 8-byte hit record per secondary Hit (gradient + class; the reference's colour + six taps),
+    one env texel per exit, one 8-byte atomic per granted sample.  For a transfer function that reads `gradient` SURVEY 8d's
+    formula credits seven volume texels per step; the kernel reads the class byte baked at repack time instead."""
+    return ((c["n_sdf"] - c["n_sdf_primary"]) + 8 * c["n_hit_bounce"] + 4 * (c["n_env"] - c["n_env_primary"]) + 8 * c["n_add"])
 
 
 def measured_traffic(key):
@@ -256,8 +273,43 @@ def run_voxel_single(ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, N, W,
         "voxels_touched": int((counts > 0).sum().item()),
         "voxels_at_cap": int((counts >= 256).sum().item()),
     }
+    exact_frame = d_frame.pull().copy()
+    # the same job with the passes FUSED into launches of 64 (clwh_render_desc.n_seeds; legal: every request is granted while the
+    # voxel's count is below 256 in any order, so counts are exact and entries below the cap identical -- tested): frame jobs as
+    # the headline times them (fresh cache, camera changed, resolve at the end)
+    S = ffi.MAX_SEEDS
+
+    def fused_job(wf=True):
+        cache.zero_()
+        ctx.invalidate_derived(scene=False, camera=True)
+        for i in range(0, len(seeds), S):
+            kernel.render(frame=d_frame, volume=d_vol, sdf=d_sdf, env=d_env, buffer_volume=m_cache, cam_pos=pos, cam_dir=cdir,
+                          seed=0, seeds=seeds[i:i + S], width=W, height=H, mode=ffi.ACCUM_VOXEL_CACHE,
+                          write_frame=wf and i + S >= len(seeds))
+
+    fused_job()
+    torch.cuda.synchronize()
+    reps = 20
+    ctx.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fused_job()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    timers = ctx.timing_read_all()
+    ctx.set_timing(False)
+    fcounts = (cache.view(-1, 2)[:, 1] >> 16) & 0xFFFF
+    out["fused"] = {
+        "what": "the same %d passes in launches of %d (one frame job = cache reset + k_primary + fused k_bounce + resolve), "
+                "%d jobs one after the other" % (len(seeds), S, reps),
+        "value": round(W * H * len(seeds) * reps / el / 1e6, 3), "unit": "Msamples/s",
+        "ms_per_job": round(el * 1e3 / reps, 4),
+        "k_bounce_ms_per_launch": round(timers["bounce"][0] / max(timers["bounce"][1], 1), 4),
+        "counts_equal_one_pass_per_launch": bool(torch.equal(fcounts, counts)),
+    }
+    m_cache.release()
     del cache
-    return out
+    return out, exact_frame
 
 
 def run_voxel_multi(args, ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, N, W, H, SPP, K, WU, rank, world, dev,
@@ -484,8 +536,11 @@ def main():
         a = (j * SPP) % max(1, len(seed_stream) - SPP)
         return seed_stream[a:a + SPP]
 
+    view = {"pos": pos, "dir": cdir}  # the camera of the frame jobs (the secondary measurement below switches to the close pose)
+
     def frame_job(j, pull=False, serial=False):
         """one step: camera -> primary hits -> SPP passes -> (gather) -> RGBA8 frame in HBM"""
+        pos, cdir = view["pos"], view["dir"]
         ln = lanes[0 if serial else j % n_lanes]
         with torch.cuda.stream(ln["stream"]):
             ln["ctx"].invalidate_derived(scene=False, camera=True)  # the first frame after a camera move: k_primary runs
@@ -506,6 +561,8 @@ def main():
                 return ln["frame"].pull()
         return None
 
+    own_job_s = []  # this rank's own time for the jobs of a region (enqueue -> its GPU idle), before the closing barrier
+
     def timed_region(first_job, k, pull=False, serial=False):
         torch.cuda.synchronize()
         barrier()
@@ -514,6 +571,7 @@ def main():
         for j in range(first_job, first_job + k):
             frame_job(j, pull, serial)
         torch.cuda.synchronize()
+        own_job_s.append((time.perf_counter() - t0) / k)
         barrier()
         torch.cuda.synchronize()
         return time.perf_counter() - t0
@@ -535,6 +593,7 @@ def main():
         region_s.append(timed_region(job, K))
         job += K
     regions = len(region_s)
+    own_ms_headline = statistics.median(own_job_s[-regions:]) * 1e3
     # kernel durations for the roofline: HIP events around every launch, in a separate region in which the frame jobs run
     # strictly one after the other on one stream -- with two frames in flight a launch's events would also span the time it
     # shares the GPU with the other frame's kernels
@@ -549,10 +608,13 @@ def main():
 
     samples_per_job = W * H * SPP
     value = samples_per_job * K / elapsed / 1e6
-    ranks_seen = [world]
+    ranks_seen = [{"rank": 0, "backend": "none", "world_size_seen": 1, "device": local_rank, "own_ms_per_job": round(own_ms_headline, 4)}]
     if world > 1:
+        # what every rank saw, so that a scaling run explains itself: the collective backend and world size, its device, and ITS
+        # OWN median time per job (enqueue to idle, without waiting for the other ranks at the closing barrier)
         seen = [None] * world
-        dist.all_gather_object(seen, (rank, dist.get_backend(), dist.get_world_size(), local_rank))
+        dist.all_gather_object(seen, {"rank": rank, "backend": dist.get_backend(), "world_size_seen": dist.get_world_size(),
+                                      "device": local_rank, "own_ms_per_job": round(own_ms_headline, 4)})
         ranks_seen = seen
     result = {
         "metric": "msamples_per_sec",
@@ -584,6 +646,8 @@ def main():
                       "seconds_total": round(sum(region_s), 4)},
             "sdf_build_s": round(sdf_build_s, 5),
             "sdf_layers": n_layers,
+            "hbm_in_use_gib": round((torch.cuda.mem_get_info(dev)[1] - torch.cuda.mem_get_info(dev)[0]) / 2 ** 30, 2),
+            "derived_scene": dict(zip(("id", "bytes", "contexts_sharing_it"), ctx.scene_info())),
             "ranks": ranks_seen,
             "rehearsal_on_one_gpu": bool(rehearsal),
         },
@@ -642,6 +706,12 @@ def main():
             "limiter": "dependent 1-byte gathers: the rate of L2-missing 128-byte lines (about 41 G/s of the 48-54 G/s a plain random-load "
                        "probe reaches) together with VALU issue (84 % busy), not algorithmic HBM bytes (DESIGN.md 4)",
             "bytes_per_sample": round(bytes_bounce(c) / float(own_px), 3),
+            "executed": {"what": "the same launch credited with what k_bounce fetches at texel granularity: 1 step byte per march step, "
+                                 "8 B hit record per secondary Hit, 4 B per env texel, 8 B per add (for a TF that reads `gradient`, SURVEY's "
+                                 "formula above credits seven volume texels per step that the kernel does not read)",
+                         "bytes_per_sample": round(bytes_bounce_executed(c) / float(own_px), 3),
+                         "achieved": round(bytes_bounce_executed(c) * passes_per_launch / (bounce_avg_ms * 1e-3) / 1e9, 2),
+                         "frac": round(bytes_bounce_executed(c) * passes_per_launch / (bounce_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
             "samples_per_launch": int(own_px * passes_per_launch),
             "algorithmic_gb_per_launch": round(bounce_bytes / 1e9, 4),
             "avg_launch_ms": round(bounce_avg_ms, 4),
@@ -665,6 +735,13 @@ def main():
                 "frac": round(contract_gbs / HBM_PEAK_GBS, 5)},
             "per_sample": {k: round(v / float(own_px), 4) for k, v in c.items() if k != "samples"},
         }
+        # what the headline hides: most pixels of the default view miss the volume and cost nothing per pass
+        hits_per_pass = c["n_hit"]
+        result["hit_samples_per_sec"] = {
+            "what": "traced samples only: (hit pixels of this rank's tiles x spp) per second of the same timed jobs; a miss pixel is "
+                    "computed once per camera (k_primary) and counted spp times in `value`",
+            "value": round(hits_per_pass * world * SPP * K / elapsed / 1e6, 3) if world == 1 else None,
+            "unit": "Msamples/s", "hit_pixel_share": round(hits_per_pass / float(own_px), 4)}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = {
                 "value": round(W * H * passes / cpu_s / 1e6, 3),
@@ -675,6 +752,45 @@ def main():
                           "CPU restatement (oracle/), not POCL" % (passes, SPP),
             }
         del osc
+
+    # ---- the same job from a pose whose frame the volume fills (scene.close_camera): its own value and k_bounce roofline
+    if world == 1 and not args.no_secondary and rank == 0:
+        view["pos"], view["dir"] = scene.close_camera(N)
+        timed_region(job, n_lanes)  # every lane once: work buffers grow to this view's hit count
+        job += n_lanes
+        kf = max(2, min(K, 10))
+        t_close = []
+        while sum(t_close) < 0.3 and len(t_close) < 20:
+            t_close.append(timed_region(job, kf))
+            job += kf
+        ctx.set_timing(True)
+        timed_region(job, 2, serial=True)
+        job += 2
+        tm = ctx.timing_read_all()
+        ctx.set_timing(False)
+        from oracle import orc_ffi
+
+        osc = orc_ffi.Scene(vol, d_sdf.pull(), env, orc_ffi.parse_tf(tf_source), (W, H), mode=orc_ffi.MODE_IMAGE_SPACE, threads=threads)
+        osc.render(view["pos"], view["dir"], job_seeds(0)[0])
+        cc = osc.counter_dict()
+        cc["samples"] = W * H
+        del osc
+        el_close = statistics.median(t_close)
+        b_ms = tm["bounce"][0] / max(tm["bounce"][1], 1)
+        ppl = SPP / float((SPP + S - 1) // S)
+        gbs = bytes_bounce(cc) * ppl / (b_ms * 1e-3) / 1e9
+        result["frame_filling_view"] = {
+            "what": "the same frame job from scene.close_camera (0.6 N in front of the volume's centre, default viewing direction)",
+            "camera": {"pos": [round(float(x), 3) for x in view["pos"]], "dir": [round(float(x), 5) for x in view["dir"]]},
+            "hit_pixel_share": round(cc["n_hit"] / float(W * H), 4),
+            "value": round(samples_per_job * kf / el_close / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(el_close * 1e3 / kf, 4),
+            "hit_samples_per_sec": round(cc["n_hit"] * SPP * kf / el_close / 1e6, 3),
+            "roofline": {"kernel": "k_bounce", "bound": "hbm", "avg_launch_ms": round(b_ms, 4), "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes_per_sample": round(bytes_bounce(cc) / float(W * H), 3),
+                         "executed_bytes_per_sample": round(bytes_bounce_executed(cc) / float(W * H), 3),
+                         "k_primary_ms": round(tm["primary"][0] / max(tm["primary"][1], 1), 4)},
+        }
+        view["pos"], view["dir"] = pos, cdir
 
     # ---- end to end incl. the final frame readback (SURVEY 8d metric ii); same jobs, frame pulled after each
     if not args.no_secondary:
@@ -690,13 +806,44 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_secondary and args.config in (2, 3):
         # cap ON: the reference's own accumulation (256 tokens per voxel), the job's SPP passes one per launch
-        result["reference_exact_mode"] = run_voxel_single(ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, N, W, H,
-                                                          job_seeds(0), torch, ffi)
+        result["reference_exact_mode"], exact_frame = run_voxel_single(ctx, kernel, d_vol, d_sdf, d_env, d_frame, pos, cdir, N, W, H,
+                                                                       job_seeds(0), torch, ffi)
+        # ---- the stated tolerance (north_star): the headline's image-space frame against the reference-exact frame of the SAME
+        # job (same seeds); different estimators of the same radiance -- per pixel 64 samples vs per voxel up to 256 shared samples
+        ln = lanes[0]
+        with torch.cuda.stream(ln["stream"]):
+            ln["accum"].zero_()
+            ln["kernel"].render(frame=None, volume=ln["vol"], sdf=ln["sdf"], env=ln["env"], accum=ln["m_accum"], cam_pos=pos, cam_dir=cdir,
+                                seed=0, seeds=job_seeds(0)[:S], width=W, height=H, mode=ffi.ACCUM_IMAGE_SPACE, write_frame=False)
+            for i in range(S, SPP, S):
+                ln["kernel"].render(frame=None, volume=ln["vol"], sdf=ln["sdf"], env=ln["env"], accum=ln["m_accum"], cam_pos=pos,
+                                    cam_dir=cdir, seed=0, seeds=job_seeds(0)[i:i + S], width=W, height=H, mode=ffi.ACCUM_IMAGE_SPACE,
+                                    write_frame=False)
+            ln["ctx"].accum_resolve(ln["m_accum"], 1, W, H, ln["frame"], ln["env"], pos, cdir)
+            image_frame = ln["frame"].pull()
+        both = (image_frame[..., 3] == 1) & (exact_frame[..., 3] == 1)
+        diff = np.abs(image_frame[both][:, :3].astype(np.int16) - exact_frame[both][:, :3].astype(np.int16)).max(axis=1)
+        result["tolerance_vs_reference_exact"] = {
+            "what": "RGBA8 frame of this job, image-space accumulation (the headline) vs the reference's capped voxel cache (one pass "
+                    "per launch), same seeds; max over r, g, b per hit pixel; miss pixels and the hit mask are identical",
+            "spp": SPP, "hit_pixels": int(both.sum()), "hit_mask_identical": bool(np.array_equal(image_frame[..., 3], exact_frame[..., 3])),
+            "max_abs_diff_lsb": int(diff.max()), "mean_abs_diff_lsb": round(float(diff.mean()), 3),
+            "share_within_1_lsb": round(float((diff <= 1).mean()), 4), "share_within_4_lsb": round(float((diff <= 4).mean()), 4),
+            "share_within_16_lsb": round(float((diff <= 16).mean()), 4)}
         if args.config == 2:
             result["drop_in_path"] = run_dropin(vol, env, tf_source, pos, torch)
+    # every rank checks every lane for a fix-up-buffer overflow (its samples would be missing from the gathered frame): no rank
+    # prints a number when any of them overflowed
+    failed = 0.0
+    for ln in lanes:
+        try:
+            ln["ctx"].finish()
+        except ffi.ClwhError as e:
+            log("[bench] rank %d: %s" % (rank, e))
+            failed = 1.0
+    if max_over_ranks([failed])[0] != 0.0:
+        raise SystemExit("bench.py: a render overflowed its fix-up buffer on some rank: results are incomplete, no line printed")
     if rank == 0:
-        for ln in lanes:
-            ln["ctx"].finish()  # raises if a render overflowed its fix-up buffer (results would be incomplete)
         print(json.dumps(result), flush=True)
 
     barrier()

@@ -76,7 +76,12 @@ struct RenderArgs {
   float cam_dir[3];
   int32_t mode;            // clwh_accum_mode
   float4 *accum;           // tile-major float4 per pixel slot (mode 1)
-  unsigned long long *delta;  // mode 1: this launch's packed sums per hit (see finish_item / k_commit)
+  unsigned long long *delta;  // mode 1 (and planned voxel-cache launches): this launch's packed sums per hit (see finish_item / k_commit)
+  // planned voxel-cache launches (several seeds fused into one launch, clwh_render): the tokens of the launch are dealt out BEFORE it
+  // runs -- grants[h] = how many of the launch's seeds hit h may trace (the first grants[h] of them) -- instead of three atomics per
+  // sample on a cache entry that all the seeds and pixels of a voxel hammer at the same time; nullptr: the reference's own
+  // token-per-sample protocol (utility.cl:20-36)
+  const uint32_t *grants;
   uint32_t *pix_slot;      // tile-major, per pixel: PIX_HIT | hit index, or the miss colour
   HitRec *hits;            // compacted primary hits of this camera
   uint32_t *counters;      // [0] hits (k_primary), [2] fix-up records, [32*(q+1)] unit-queue heads, one per 128-B line
@@ -156,6 +161,15 @@ hipError_t launch_primary(const RenderArgs &a, hipStream_t s);
 hipError_t launch_bounce(const RenderArgs &a, hipStream_t s);
 hipError_t launch_env_fixup(const RenderArgs &a, hipStream_t s);
 hipError_t launch_commit(const RenderArgs &a, hipStream_t s);
+// planned voxel-cache launches: sort keys of the camera's hits (their cache entries), the token deal of one launch, the launch's sums into the cache
+constexpr int64_t kVoxKeyInvalid = (int64_t)1 << 38;  // a hit whose entry lies outside the cache; kVoxKeyNone: no such hit (padding)
+constexpr int64_t kVoxKeyNone = ((int64_t)1 << 38) + 1;
+hipError_t launch_vox_keys(const RenderArgs &a, int64_t *keys, uint32_t *iota, uint32_t n, hipStream_t s);
+hipError_t launch_vox_grant(const RenderArgs &a, const int64_t *sorted_keys, const uint32_t *order, uint32_t n, uint32_t *grants, hipStream_t s);
+hipError_t launch_commit_voxel(const RenderArgs &a, hipStream_t s);
+// stable radix sort of (entry, position) pairs on bits [0, end_bit) (exchange_kernels.hip: the one translation unit with rocPRIM)
+hipError_t sort_entry_pairs(void *temp, size_t &temp_bytes, const int64_t *keys_in, int64_t *keys_out, const uint32_t *vals_in,
+                            uint32_t *vals_out, size_t n, unsigned end_bit, hipStream_t s);
 hipError_t launch_resolve(const RenderArgs &a, hipStream_t s);
 hipError_t launch_ao(const RenderArgs &a, hipStream_t s);
 hipError_t launch_accum_resolve(const RenderArgs &a, const float4 *accum_all, hipStream_t s);
@@ -257,6 +271,13 @@ struct clwh_ctx {
   size_t fixups_bytes = 0;
   unsigned long long *delta = nullptr;
   size_t delta_bytes = 0;
+  // planned voxel-cache launches: the camera's hits grouped by voxel (sorted once per camera), this launch's grants
+  uint8_t *vox_plan = nullptr;     // keys_in | keys_sorted (int64 each) | iota | order | grants (u32 each), n_capacity elements each
+  size_t vox_plan_bytes = 0;
+  void *vox_temp = nullptr;
+  size_t vox_temp_bytes = 0;
+  bool vox_plan_valid = false;
+  uint32_t vox_plan_n = 0;         // elements sorted (the hit count, or its bound when the plan was made)
   // hiprtc-compiled transfer functions, by source text; and the class bytes of the current (volume, source)
   std::map<std::string, std::shared_ptr<clvr::JitTf>> jit_cache;
   uint8_t *jit_cls = nullptr;

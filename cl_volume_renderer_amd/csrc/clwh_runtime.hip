@@ -241,6 +241,8 @@ int clwh_ctx_destroy(clwh_ctx *ctx) {
   if (ctx->sticky_flags) (void)hipFree(ctx->sticky_flags);
   if (ctx->fixups) (void)hipFree(ctx->fixups);
   if (ctx->delta) (void)hipFree(ctx->delta);
+  if (ctx->vox_plan) (void)hipFree(ctx->vox_plan);
+  if (ctx->vox_temp) (void)hipFree(ctx->vox_temp);
   if (ctx->jit_cls) (void)hipFree(ctx->jit_cls);
   if (ctx->jit_palette) (void)hipFree(ctx->jit_palette);
   for (auto &kv : ctx->jit_cache)
@@ -861,6 +863,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     HIP_TRY(hipMemcpyAsync(ctx->host_n_hits, ctx->render_counters, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->n_hits_event, ctx->stream));
     ctx->n_hits_in_flight = true;
+    ctx->vox_plan_valid = false;
     ctx->primary_n_hits_known = false;
     ctx->primary_key = key;
     ctx->primary_valid = true;
@@ -914,13 +917,42 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     if (rc != CLWH_OK) return rc;
     a.fixups = ctx->fixups;
     a.fixup_capacity = (uint32_t)std::min<size_t>(ctx->fixups_bytes / 128u, 0x7fffffffu);
-    if (a.mode == CLWH_ACCUM_IMAGE_SPACE) {
+    // a voxel-cache launch of several seeds deals its tokens out beforehand (render_kernels.hip "planned voxel-cache launches");
+    // one seed per launch -- the reference's call pattern, and the per-pixel contribution output of the parity tests -- keeps the
+    // reference's token-per-sample protocol
+    const bool planned = a.mode == CLWH_ACCUM_VOXEL_CACHE && a.n_seeds > 1;
+    if (a.mode == CLWH_ACCUM_IMAGE_SPACE || planned) {
       // one 64-bit delta per hit; k_commit folds a launch's deltas into the accumulator and leaves them zero for the next launch
       const size_t before = ctx->delta_bytes;
       rc = grow(ctx, (void **)&ctx->delta, &ctx->delta_bytes, std::max<size_t>(slots, 1) * sizeof(unsigned long long));
       if (rc != CLWH_OK) return rc;
       a.delta = ctx->delta;
       if (ctx->delta_bytes != before) HIP_TRY(hipMemsetAsync(ctx->delta, 0, ctx->delta_bytes, ctx->stream));
+    }
+    if (planned) {
+      // keys_in | keys_sorted (int64) | iota | order | grants (u32), `cap` elements each; sorted once per camera
+      const size_t cap = slots;
+      const uint8_t *plan_before = ctx->vox_plan;
+      rc = grow(ctx, (void **)&ctx->vox_plan, &ctx->vox_plan_bytes, cap * (2 * sizeof(int64_t) + 3 * sizeof(uint32_t)));
+      if (rc != CLWH_OK) return rc;
+      if (ctx->vox_plan != plan_before) ctx->vox_plan_valid = false;
+      const size_t have = ctx->vox_plan_bytes / (2 * sizeof(int64_t) + 3 * sizeof(uint32_t));
+      int64_t *keys_in = reinterpret_cast<int64_t *>(ctx->vox_plan), *keys = keys_in + have;
+      uint32_t *iota = reinterpret_cast<uint32_t *>(keys + have), *order = iota + have, *grants = order + have;
+      if (!ctx->vox_plan_valid) {
+        const uint32_t n = a.n_hits;  // the count, or its bound (then the tail sorts behind every real hit)
+        HIP_TRY(launch_vox_keys(a, keys_in, iota, n, ctx->stream));
+        size_t need = 0;
+        HIP_TRY(sort_entry_pairs(nullptr, need, keys_in, keys, iota, order, n, 39u, ctx->stream));
+        rc = grow(ctx, &ctx->vox_temp, &ctx->vox_temp_bytes, std::max<size_t>(need, 16));
+        if (rc != CLWH_OK) return rc;
+        size_t tb = ctx->vox_temp_bytes;
+        HIP_TRY(sort_entry_pairs(ctx->vox_temp, tb, keys_in, keys, iota, order, n, 39u, ctx->stream));
+        ctx->vox_plan_valid = true;
+        ctx->vox_plan_n = n;
+      }
+      HIP_TRY(launch_vox_grant(a, keys, order, ctx->vox_plan_n, grants, ctx->stream));
+      a.grants = grants;
     }
     TimedLaunch t;
     rc = t.begin(ctx, CLWH_TIMER_BOUNCE);
@@ -945,6 +977,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     if (rc != CLWH_OK) return rc;
     HIP_TRY(launch_env_fixup(a, ctx->stream));
     HIP_TRY(launch_commit(a, ctx->stream));
+    if (planned) HIP_TRY(launch_commit_voxel(a, ctx->stream));
     rc = tf.end();
     if (rc != CLWH_OK) return rc;
     ctx->fixup_overflow_pending = true;

@@ -36,14 +36,29 @@ __device__ __forceinline__ f3 normalize3(f3 a) {
 __device__ __forceinline__ float cl_min(float a, float b) { return (b < a) ? b : a; }
 __device__ __forceinline__ float cl_max(float a, float b) { return (a < b) ? b : a; }
 
-// float -> int32 / uint32: truncate toward zero, saturate, NaN -> 0
+// float -> int32 / uint32: truncate toward zero, saturate, NaN -> 0.  That is exactly what V_CVT_I32_F32 / V_CVT_U32_F32 do on
+// this hardware (out-of-range values and infinities saturate, NaN converts to 0, negative values convert to 0u), so the contract's
+// conversion is ONE instruction; written out in C++ it compiled to three compares, three selects and a branch around the convert --
+// two dozen instructions, ten times per event phase of k_bounce.  tests/test_gpu_device_math.py checks the instruction against the
+// written-out definition on every special value and on random bit patterns.
 __device__ __forceinline__ int32_t f2i(float v) {
+  int32_t r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+__device__ __forceinline__ uint32_t f2u(float v) {
+  uint32_t r;
+  asm("v_cvt_u32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
+// the definition, written out (the oracle's form): what the instructions above must equal
+__device__ __forceinline__ int32_t f2i_reference(float v) {
   if (v != v) return 0;
   if (v >= 2147483648.0f) return 2147483647;
   if (v <= -2147483648.0f) return (-2147483647 - 1);
   return (int32_t)v;
 }
-__device__ __forceinline__ uint32_t f2u(float v) {
+__device__ __forceinline__ uint32_t f2u_reference(float v) {
   if (v != v) return 0u;
   if (v >= 4294967296.0f) return 0xFFFFFFFFu;
   if (v <= 0.0f) return 0u;

@@ -58,6 +58,11 @@ CLVR_HD float asin_approx(float v) {
 }
 
 CLVR_HD int32_t env_f2i(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  int32_t r;  // saturating, NaN -> 0: the definition below in one instruction (device_math.hpp f2i)
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+#endif
   if (v != v) return 0;
   if (v >= 2147483648.0f) return 2147483647;
   if (v <= -2147483648.0f) return (-2147483647 - 1);

@@ -17,6 +17,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "clwh_internal.hpp"
+#include "device_math.hpp"
 
 struct clwh_exchange_plan {
   clwh_ctx *ctx = nullptr;
@@ -56,6 +57,19 @@ __global__ __launch_bounds__(256) void k_apply_contributions(const int64_t *__re
   *reinterpret_cast<uint2 *>(cache + 2 * e) = w;
 }
 
+__global__ __launch_bounds__(256) void k_debug_conversions(const float *__restrict__ in, uint64_t n, int32_t *__restrict__ oi, uint32_t *__restrict__ ou) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const float v = in[i];
+  oi[i] = f2i(v); oi[n + i] = f2i_reference(v);
+  ou[i] = f2u(v); ou[n + i] = f2u_reference(v);
+}
+
+hipError_t sort_entry_pairs(void *temp, size_t &temp_bytes, const int64_t *keys_in, int64_t *keys_out, const uint32_t *vals_in,
+                            uint32_t *vals_out, size_t n, unsigned end_bit, hipStream_t s) {
+  return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, s);
+}
+
 }  // namespace clvr
 
 using namespace clvr;
@@ -67,6 +81,17 @@ using namespace clvr;
   } while (0)
 
 extern "C" {
+
+int clwh_debug_float_conversions(clwh_ctx *ctx, clwh_mem *floats_in, uint64_t n, clwh_mem *i32_out, clwh_mem *u32_out) {
+  if (!ctx || !floats_in || !i32_out || !u32_out) return CLWH_ERR_INVALID_VALUE;
+  if (floats_in->bytes < n * 4 || i32_out->bytes < n * 8 || u32_out->bytes < n * 8 || n >= (1ull << 31)) return CLWH_ERR_SIZE_MISMATCH;
+  if (n == 0) return CLWH_OK;
+  HIP_TRY_X(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_debug_conversions, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, ctx->stream, (const float *)floats_in->dptr, n,
+                     (int32_t *)i32_out->dptr, (uint32_t *)u32_out->dptr);
+  HIP_TRY_X(hipGetLastError());
+  return CLWH_OK;
+}
 
 int clwh_cache_exchange_plan_release(clwh_exchange_plan *plan) {
   if (!plan) return CLWH_ERR_INVALID_VALUE;

@@ -115,6 +115,7 @@ _PROTOTYPES = [
     ("clwh_cache_apply_contributions", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     ("clwh_cache_exchange_plan_release", C.c_int, [C.c_void_p]),
     ("clwh_tf_parse", C.c_int, [C.c_char_p, C.POINTER(Tf)]),
+    ("clwh_debug_float_conversions", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     ("clwh_strerror", C.c_char_p, [C.c_int]),
     ("clwh_last_hip_error", C.c_int, []),
     ("clwh_version", C.c_char_p, []),
@@ -138,6 +139,8 @@ def lib():
                 "there is no CPU fallback for the product path" % LIB_PATH)
         L = C.CDLL(LIB_PATH)
         for name, res, args in _PROTOTYPES:
+            if not hasattr(L, name) and os.environ.get("CLWH_LIBRARY"):
+                continue  # an older build named explicitly for an A/B timing run (tools/ab_bounce.sh)
             f = getattr(L, name)
             f.restype = res
             f.argtypes = args

@@ -278,6 +278,10 @@ typedef struct clwh_tf {
 int clwh_tf_parse(const char *source, clwh_tf *out);
 
 /* ---- diagnostics */
+/* self-test of the library's float -> integer conversions (DESIGN.md "Semantics": truncate, saturate, NaN -> 0), which the kernels
+ * perform with single hardware instructions: converts n floats on the device both ways -- the instruction and the definition
+ * written out -- into int32 / uint32 arrays of 2 n elements each ([0, n): instruction, [n, 2n): definition) */
+int clwh_debug_float_conversions(clwh_ctx *ctx, clwh_mem *floats_in, uint64_t n, clwh_mem *i32_out, clwh_mem *u32_out);
 const char *clwh_strerror(int status);
 int clwh_last_hip_error(void);
 const char *clwh_version(void);

@@ -69,6 +69,7 @@ enum {
   ORC_N_SDF_PRIMARY = 8,
   ORC_N_VOL_PRIMARY = 9,
   ORC_N_ENV_PRIMARY = 10,
+  ORC_N_HIT_BOUNCE = 11, /* Hit events of the distribution rays (what k_bounce pays one 8-byte hit record for) */
   ORC_N_COUNTERS = 12
 };
 

@@ -22,7 +22,7 @@ LOCALITY_TOTAL, LOCALITY_HIST_RAY, LOCALITY_HIST_ITEM, LOCALITY_CERT_WRONG = 16 
 LOCALITY_NAMES = ("fetches", "same_sub4", "same_brick8", "near_8", "near_16", "near_32", "near_64", "uniform4",
                   "step_le_1", "step_le_2", "step_le_8", "step_le_32", "steps", "cert_tried", "cert_granted", "cert_saved")
 COUNTER_NAMES = ("n_sdf", "n_vol", "n_env", "n_tok", "n_add", "n_read", "n_hit", "n_step",
-                 "n_sdf_primary", "n_vol_primary", "n_env_primary", "reserved")
+                 "n_sdf_primary", "n_vol_primary", "n_env_primary", "n_hit_bounce")
 MODE_VOXEL_CACHE, MODE_IMAGE_SPACE = 0, 1
 SHADE_LIGHT, SHADE_AO = 0, 1
 

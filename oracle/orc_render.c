@@ -579,6 +579,7 @@ static u4 compute_light(ctx_t *c, ray_t surface_ray, int32_t random_seed, int64_
                                atten * b_energy * (float)light_map.z * factor / (float)information_dev);
           break;
         } else if (ray_event == EV_HIT) {
+          c->c[ORC_N_HIT_BOUNCE]++;
           const f3 normal2 = v_neg(v_normalize(gradient_nn(c, current_ray.origin)));
           current_ray = bounce_fake_reflectance(c, current_ray, normal2, random_seed + o + i,
                                                 ((float)current_color.w) / 255.0f);
