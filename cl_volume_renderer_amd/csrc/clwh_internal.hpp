@@ -289,7 +289,7 @@ struct clwh_ctx {
   clvr::TfDev jit_tf{};
   bool fixup_overflow_pending = false;
   uint32_t *sticky_flags = nullptr;  // [0] fix-up buffer overflow: set by kernels, cleared only when the host has read it
-  // measured on MI355X (profiles/r01_tune_*.txt): a wave that runs its 64 samples to completion with
+  // measured on MI355X (round 1, git history: profiles/r01_tune_*.txt): a wave that runs its 64 samples to completion with
   // steps and events in separate wave-wide phases beats mid-flight refills (12.5 vs 7.6 Gsamples/s)
   int32_t tune_step_min_lanes = 0;    // 0: chosen per launch (launch_bounce)
   int32_t tune_refill_min_lanes = 0;  // 0: chosen per launch (launch_bounce)

@@ -298,6 +298,9 @@ __global__ __launch_bounds__(64) void k_primary(const RenderArgs a) {
   bool hit = false;
   Ray current_ray{cut_point, vray.direction};
   uint32_t current_color = 0u;
+  // (tried in round 3: the exit-certificate table on the camera ray at its entry point -- "no event in the box towards the octant's
+  // corner" would make the pixel a miss without a march.  From the default pose that box nearly always holds the object: 0.100 ms with
+  // and without, tools/ab_list.sh; not kept)
   if (cut_ok) {
     int ev;
     current_ray = march_to_next_event<USE_GRAD>(vol, a.tf, current_ray, ev, current_color);
@@ -664,6 +667,14 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
 #ifdef CLVR_BOUNCE_STATS
         st_step_iters += 1; st_step_lanes += (uint32_t)__popcll(__ballot(st == ST_MARCH));
 #endif
+#ifdef CLVR_EXP_STEP_PAD  // experiment: N extra dependent FMAs per step iteration
+        {
+          float pad = ray.origin.x;
+#pragma unroll
+          for (int q = 0; q < CLVR_EXP_STEP_PAD; ++q) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pad));
+          if (pad == 123.456f) atten = pad;
+        }
+#endif
         if (st == ST_MARCH) {
           // sd is an integer in 0..127: fmaxf is cl_max here
           ray.origin = ray.origin + ray.direction * fmaxf((float)sd, 0.5f);
@@ -728,6 +739,14 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
     }
 
     // ---- event phase: every parked lane handles its event; the bounce is one shared block ---------
+#ifdef CLVR_EXP_EVENT_PAD  // experiment: how sensitive is the launch to VALU work in the event phase?  N extra dependent FMAs per phase
+    {
+      float pad = ray.origin.x;
+#pragma unroll
+      for (int q = 0; q < CLVR_EXP_EVENT_PAD; ++q) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(pad));
+      if (pad == 123.456f) atten = pad;
+    }
+#endif
 #ifdef CLVR_BOUNCE_STATS
     st_event_phases += 1; st_event_lanes += (uint32_t)__popcll(__ballot(st >= ST_EVENT));
     st_ev_kind[0] += (uint32_t)__popcll(__ballot(st == ST_EVENT + EV_START));
@@ -1105,7 +1124,7 @@ hipError_t launch_bounce(const RenderArgs &a_in, hipStream_t s) {
   // bound by its longest dependent chain: every wave steps its samples to completion and refills when empty.
   // A long launch is bound by VALU issue: lanes refill at 16 idle and the march phase ends at 16 marching lanes.
   // Measured crossover on the headline scene: between 4 and 8 passes per launch = about 6 units per wave
-  // (profiles/r01_tune_refill_step_thresholds.txt).
+  // (round-1 sweep, git history: profiles/r01_tune_refill_step_thresholds.txt; re-swept in profiles/r02_tune_k_bounce_knobs.txt).
   // (with the hit count still on the device n_hits is the pixel count, an upper bound; the class follows the estimate: the last
   // camera's count with slack, clwh_render)
   const uint64_t waves_likely = ((uint64_t)a.n_hits_estimate * (uint64_t)a.n_seeds + 63u) / 64u;

@@ -7,6 +7,10 @@ OUT=${GRAFT_REPO_ROOT:-$PWD}/gpurun_out/miss_bytes
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 P=./tools/probes/miss_bytes_probe
+# the probe binary is not tracked (tools/probes/*_probe is git-ignored): build it when it is missing or older than its source
+if [ ! -x "$P" ] || [ "$P.hip" -nt "$P" ]; then
+  /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 "$P.hip" -o "$P" || exit 1
+fi
 $P > "$OUT/timing.txt" || exit 1
 cat "$OUT/timing.txt"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/p_fetch" -- $P > /dev/null 2> "$OUT/p_fetch.err" || { tail -5 "$OUT/p_fetch.err"; exit 1; }
