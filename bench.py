@@ -140,11 +140,16 @@ def bytes_primary(c):
     return c["n_sdf_primary"] + 2 * c["n_vol_primary"] + 4 * c["n_env_primary"] + 4 * c["samples"]
 
 
-def bytes_bounce(c):
+def bytes_bounce(c, tf_reads_gradient=False):
     """what k_bounce performs per pass: the distribution rays' marches, their normals, the environment texels of
-    the rays that leave, one 8-byte atomic per granted sample"""
-    return ((c["n_sdf"] - c["n_sdf_primary"]) + 2 * (c["n_vol"] - c["n_vol_primary"])
-            + 4 * (c["n_env"] - c["n_env_primary"]) + 8 * c["n_add"])
+    the rays that leave, one 8-byte atomic per granted sample.  tf_reads_gradient: SURVEY 8d's formula credits a transfer
+    function that reads `gradient` with seven volume texels per classified step (the value and six taps); k_bounce reads
+    the class baked at repack time instead, so it is credited like any other table -- one volume texel per classified
+    step plus the six taps of every Hit's normal ("every kernel is credited only with what it executes")"""
+    n_vol = c["n_vol"] - c["n_vol_primary"]
+    if tf_reads_gradient:
+        n_vol = (n_vol - 6 * c["n_hit_bounce"]) / 7.0 + 6 * c["n_hit_bounce"]
+    return ((c["n_sdf"] - c["n_sdf_primary"]) + 2 * n_vol + 4 * (c["n_env"] - c["n_env_primary"]) + 8 * c["n_add"])
 
 
 def bytes_bounce_executed(c):
@@ -157,11 +162,14 @@ def bytes_bounce_executed(c):
 
 def measured_traffic(key):
     """HBM-side bytes per launch of a kernel from the rocprofv3 PMC passes committed under profiles/ (bench.py
-    cannot run the profiler on itself): {workload key: {kernel: {...}}} in profiles/r02_traffic.json."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if not os.path.exists(path):
-        return None
-    return json.load(open(path)).get(key)
+    cannot run the profiler on itself): {workload key: {kernel: {...}}} in profiles/r03_traffic.json (round 2's file for shapes not profiled again)."""
+    for name in ("r03_traffic.json", "r02_traffic.json"):  # the newest profile that holds this launch shape
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            entry = json.load(open(path)).get(key)
+            if entry:
+                return entry
+    return None
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -406,7 +414,7 @@ def main():
                          "cache, one pass per launch, contributions exchanged pass by pass under the global 256-token rule")
     ap.add_argument("--seeds-per-launch", type=int, default=64, help="render passes fused into one launch (1..64)")
     ap.add_argument("--frames-in-flight", type=int, default=None,
-                    help="default 2 (3 from six ranks on): consecutive frame jobs alternate between this many HIP streams (each with its own accumulation and "
+                    help="default 3 on one GPU and from six ranks on, else 2: consecutive frame jobs alternate between this many HIP streams (each with its own accumulation and "
                          "frame buffers), so that the next frame's primary hits and first waves fill the GPU while the last "
                          "waves of the previous frame's persistent launch drain; 1 = strictly one frame after the other")
     args = ap.parse_args()
@@ -476,7 +484,9 @@ def main():
     # for 8 ranks with three jobs on 768 blocks each (tools/emulate_rank.py, profiles/r02_emulate_rank_grid_sweep.txt); the single-GPU
     # job is indifferent and keeps the library default.  Placement knobs, read when a context is created; results do not depend on them.
     if args.frames_in_flight is None:
-        args.frames_in_flight = 3 if world >= 6 else 2
+        # one GPU: 1 / 2 / 3 jobs in flight = 31.5 / 32.5 / 33.0 Gsamples/s on the headline job (profiles/r03_frame_lanes.txt; the derived
+        # scene data is shared, a lane costs its own accumulation / frame / hit buffers only); ranks of a multi-GPU job: see below
+        args.frames_in_flight = 3 if (world >= 6 or world == 1) else 2
     if world > 1 and args.frames_in_flight >= 2:
         os.environ.setdefault("CLWH_TUNE_BLOCKS", "1024" if args.frames_in_flight == 2 else "768")
     # everything below runs on torch's current stream so torch.cuda.synchronize() covers it
@@ -680,7 +690,8 @@ def main():
         f_ms, f_n = timers["fixup"]
         r_ms, r_n = timers["resolve"]
         passes_per_launch = SPP / float((SPP + S - 1) // S)
-        bounce_bytes = bytes_bounce(c) * passes_per_launch          # per launch
+        grad = args.tf == "gradient"
+        bounce_bytes = bytes_bounce(c, grad) * passes_per_launch    # per launch
         bounce_avg_ms = b_ms / max(b_n, 1)
         bounce_gbs = bounce_bytes / (bounce_avg_ms * 1e-3) / 1e9
         primary_bytes = bytes_primary(c)
@@ -705,7 +716,12 @@ def main():
             "traffic_note": (tb or {}).get("note", "GB per launch from rocprofv3 --pmc (profiles/r02_traffic.json); null: this launch shape was not profiled"),
             "limiter": "dependent 1-byte gathers: the rate of L2-missing 128-byte lines (about 41 G/s of the 48-54 G/s a plain random-load "
                        "probe reaches) together with VALU issue (84 % busy), not algorithmic HBM bytes (DESIGN.md 4)",
-            "bytes_per_sample": round(bytes_bounce(c) / float(own_px), 3),
+            "bytes_per_sample": round(bytes_bounce(c, grad) / float(own_px), 3),
+            "survey_formula_with_per_step_gradient_taps": ({
+                "what": "SURVEY 8d's formula as written credits a TF that reads `gradient` with 7 volume texels per classified step; "
+                        "k_bounce does not perform those fetches (class byte baked by k_repack), so `achieved` / `frac` above leave them out",
+                "bytes_per_sample": round(bytes_bounce(c) / float(own_px), 3),
+                "frac": round(bytes_bounce(c) * passes_per_launch / (bounce_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)} if grad else None),
             "executed": {"what": "the same launch credited with what k_bounce fetches at texel granularity: 1 step byte per march step, "
                                  "8 B hit record per secondary Hit, 4 B per env texel, 8 B per add (for a TF that reads `gradient`, SURVEY's "
                                  "formula above credits seven volume texels per step that the kernel does not read)",
@@ -717,8 +733,9 @@ def main():
             "avg_launch_ms": round(bounce_avg_ms, 4),
             "launches": b_n,
             "what_is_counted": "only what k_bounce executes per pass: N_sdf + 2 N_vol + 4 N_env of the bounce phase + 8 N_add "
-                               "(oracle counters split by phase); the primary march, its normal and the miss pixels' env "
-                               "texels belong to k_primary (once per camera)",
+                               "(oracle counters split by phase; N_vol = one texel per classified step + six per Hit normal, whatever "
+                               "the TF reads); the primary march, its normal and the miss pixels' env texels belong to k_primary "
+                               "(once per camera)",
             "per_kernel": {
                 "k_primary": {"algorithmic_gb_per_launch": round(primary_bytes / 1e9, 4), "avg_launch_ms": round(primary_avg_ms, 4),
                               "launches": p_n, "achieved": round(primary_bytes / max(primary_avg_ms, 1e-9) / 1e6, 2),

@@ -23,6 +23,12 @@ def test_byte_accounting_splits_the_path_by_kernel():
     assert abs(primary - (4.61 + 2 * 5.10 + 4 * 0.84 + 4)) < 1e-6                  # what k_primary executes, once per camera
     # the SURVEY 8d contract counts every texel once: primary + bounce texels, the atomic, the frame write
     assert abs(contract - (primary + bounce)) < 1e-6
+    # what k_bounce fetches at texel granularity: one step byte per march step, one 8-byte hit record per secondary Hit, the env
+    # texels of the bounce phase, one 8-byte atomic per sample -- for a gradient TF the contract's seven texels per step drop out
+    c["n_hit_bounce"] = 0.15
+    assert abs(b.bytes_bounce_executed(c) - (4.81 + 8 * 0.15 + 4 * 0.287 + 8 * 0.16)) < 1e-6
+    cg = dict(c, n_vol=10.50 + 6 * 4.0)   # a TF that reads `gradient`: six more texels per classified step in the contract ...
+    assert b.bytes_bounce(cg) > b.bytes_bounce(c) + 40 and b.bytes_bounce_executed(cg) == b.bytes_bounce_executed(c)   # ... none executed
     assert set(b.PRESETS) == {2, 3, 4, 5} and b.PRESETS[2]["spp"] == 64 and b.PRESETS[4]["volume"] == 2048
 
 
