@@ -795,7 +795,7 @@ def main():
         el_close = statistics.median(t_close)
         b_ms = tm["bounce"][0] / max(tm["bounce"][1], 1)
         ppl = SPP / float((SPP + S - 1) // S)
-        gbs = bytes_bounce(cc) * ppl / (b_ms * 1e-3) / 1e9
+        gbs = bytes_bounce(cc, args.tf == "gradient") * ppl / (b_ms * 1e-3) / 1e9
         result["frame_filling_view"] = {
             "what": "the same frame job from scene.close_camera (0.6 N in front of the volume's centre, default viewing direction)",
             "camera": {"pos": [round(float(x), 3) for x in view["pos"]], "dir": [round(float(x), 5) for x in view["dir"]]},
@@ -803,7 +803,7 @@ def main():
             "value": round(samples_per_job * kf / el_close / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(el_close * 1e3 / kf, 4),
             "hit_samples_per_sec": round(cc["n_hit"] * SPP * kf / el_close / 1e6, 3),
             "roofline": {"kernel": "k_bounce", "bound": "hbm", "avg_launch_ms": round(b_ms, 4), "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes_per_sample": round(bytes_bounce(cc) / float(W * H), 3),
+                         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "bytes_per_sample": round(bytes_bounce(cc, args.tf == "gradient") / float(W * H), 3),
                          "executed_bytes_per_sample": round(bytes_bounce_executed(cc) / float(W * H), 3),
                          "k_primary_ms": round(tm["primary"][0] / max(tm["primary"][1], 1), 4)},
         }
