@@ -101,6 +101,7 @@ struct RenderArgs {
   int32_t step_min_lanes;    // keep stepping while at least this many lanes march
   int32_t refill_min_lanes;  // idle lanes fetch new items once this many are idle (64: only an empty wave refills)
   int32_t force_long_launch; // tests: schedule every launch like a long one (thresholds 16 / 16, exit certificates)
+  int32_t bounce_rays;       // 2: long launches run k_bounce2, two rays per lane (CLWH_TUNE_BOUNCE_RAYS; the round-3 experiment)
   uint32_t bounce_max_blocks;  // persistent grid size (256-thread blocks)
   int32_t unit_group;          // chunks per queue group (see k_bounce refill)
   int32_t unit_block_log2;     // 2^n consecutive chunks go to the same queue
@@ -294,6 +295,7 @@ struct clwh_ctx {
   int32_t tune_step_min_lanes = 0;    // 0: chosen per launch (launch_bounce)
   int32_t tune_refill_min_lanes = 0;  // 0: chosen per launch (launch_bounce)
   int32_t tune_macro_shift = 0;       // CLWH_TUNE_MACRO_SHIFT: 4..8 forces the macro cell's edge to 2^n voxels (0: by volume size)
+  int32_t tune_bounce_rays = 1;       // CLWH_TUNE_BOUNCE_RAYS=2: k_bounce2 for long launches
   int32_t tune_force_long_launch = 0; // CLWH_TUNE_LONG_LAUNCH=1: every launch is scheduled like a long one (the parity tests use it)
   int32_t tune_literal_gradient = 0;
   int32_t tune_unit_block_log2 = 4;

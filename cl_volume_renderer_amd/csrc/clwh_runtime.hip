@@ -207,6 +207,7 @@ int clwh_ctx_create_on_stream(int device, void *hip_stream, clwh_ctx **out) {
   if (const char *e = std::getenv("CLWH_TUNE_BLOCKS")) c->tune_bounce_max_blocks = (uint32_t)std::max(1, std::atoi(e));
   if (const char *e = std::getenv("CLWH_TUNE_MACRO_SHIFT")) c->tune_macro_shift = std::atoi(e);
   if (const char *e = std::getenv("CLWH_TUNE_LONG_LAUNCH")) c->tune_force_long_launch = std::atoi(e) != 0;
+  if (const char *e = std::getenv("CLWH_TUNE_BOUNCE_RAYS")) c->tune_bounce_rays = std::atoi(e) == 2 ? 2 : 1;
   if (const char *e = std::getenv("CLWH_TUNE_SDF")) c->tune_sdf_front = std::strcmp(e, "front") == 0;
   if (const char *e = std::getenv("CLWH_TUNE_SDFBIT_WAVES")) c->tune_sdfbit_waves = std::atoi(e) == 16 ? 16 : 8;
   if (const char *e = std::getenv("CLWH_TUNE_SDFBIT_GRID")) c->tune_sdfbit_grid = std::max(1, std::atoi(e));
@@ -784,6 +785,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
   a.step_min_lanes = ctx->tune_step_min_lanes;
   a.refill_min_lanes = ctx->tune_refill_min_lanes;
   a.force_long_launch = ctx->tune_force_long_launch;
+  a.bounce_rays = ctx->tune_bounce_rays;
   a.bounce_max_blocks = ctx->tune_bounce_max_blocks;
   a.unit_group = ctx->tune_unit_group;
   a.unit_block_log2 = ctx->tune_unit_block_log2;
@@ -962,7 +964,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
     if (rc != CLWH_OK) return rc;
 #ifdef CLVR_BOUNCE_STATS  // experiment builds only (CLVR_EXTRA_HIPCC_FLAGS=-DCLVR_BOUNCE_STATS): scheduling statistics of the launch
     {
-      uint32_t h[21];
+      uint32_t h[22];
       HIP_TRY(hipMemcpyAsync(h, ctx->render_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
       std::fprintf(stderr, "[bounce stats] items=%llu step_iters=%u avg_march_lanes=%.2f event_phases=%u avg_event_lanes=%.2f "
@@ -970,6 +972,7 @@ int clwh_render(clwh_kernel *k, const clwh_render_desc *d) {
                    (unsigned long long)h[0] * (unsigned long long)a.n_seeds, h[8], h[8] ? (double)h[9] / h[8] : 0.0, h[10],
                    h[10] ? (double)h[11] / h[10] : 0.0, h[12], h[12] ? (double)h[13] / h[12] : 0.0, h[14], h[15], h[16], h[17], h[18],
                    h[18] ? (double)h[19] / h[18] : 0.0, h[20]);
+      if (h[21]) std::fprintf(stderr, "[bounce stats] two rays per lane: %u swap points\n", h[21]);
     }
 #endif
     TimedLaunch tf;

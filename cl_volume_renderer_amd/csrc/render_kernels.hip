@@ -901,6 +901,386 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_bounce2: the same pass with TWO rays per lane (CLWH_TUNE_BOUNCE_RAYS=2; long launches only) -- the round-3 experiment on lane
+// utilisation (results in profiles/r03_k_bounce_two_rays_per_lane.txt).
+//
+// k_bounce runs its step iterations at 28.8 and its event phases at 36.7 of 64 lanes: a lane whose ray waits for the wave's event
+// phase takes no march steps, a lane whose ray marches sits out the event phase.  Here a lane owns two rays, `cur` and `alt`: the hot
+// march state of both in registers (origin, direction; state, step length and steps left -- alt's packed into one register), everything
+// only an event needs in LDS (nine dwords per ray: pixel, hit | seed index, fix-up word with o and i, the packed radiance sums,
+// attenuation, three energies, colour; the primary hit's normal and start are re-read from its 64-byte record).  The step loop works on
+// `cur`; where it ends a lane whose cur is parked swaps in a marching alt (seven v_swap) and the loop runs once more; before the event
+// phase a lane whose cur still marches swaps in a parked or idle alt -- so both phases see a ray of the right kind in most lanes.  No
+// ray ever leaves its lane: no synchronisation between waves, the per-ray arithmetic is k_bounce's, instruction for instruction.
+constexpr int kBounce2WavesPerSimd = 6;  // LDS: 18 KB of event state + 6 KB index tables + 1.3 KB per 256-thread block
+template <bool USE_GRAD, int MODE, bool SMALL_VOLUME>
+__global__ __launch_bounds__(256, kBounce2WavesPerSimd) void k_bounce2(const RenderArgs a) {
+  constexpr int SMALL = SMALL_VOLUME ? 2 : 0;
+  VolumePacked vol = make_volume(a);
+  extern __shared__ uint32_t lds_parts[];
+  if (SMALL == 2) {
+    vol.parts = lds_parts;
+    vol.parts_y0 = a.X;
+    vol.parts_z0 = a.X + a.Y;
+    for (int k = (int)threadIdx.x; k < a.X + a.Y + a.Z; k += 256)
+      lds_parts[k] = k < a.X ? vol.part_x<1>((unsigned)k) : (k < a.X + a.Y ? vol.part_y<1>((unsigned)(k - a.X)) : vol.part_z<1>((unsigned)(k - a.X - a.Y)));
+  }
+  __shared__ float div255[256];
+  __shared__ int32_t s_seeds[CLWH_MAX_SEEDS];
+  div255[threadIdx.x] = (float)threadIdx.x / 255.0f;
+  if (threadIdx.x < (unsigned)CLWH_MAX_SEEDS) s_seeds[threadIdx.x] = a.seeds[threadIdx.x < (unsigned)a.n_seeds ? threadIdx.x : 0u];
+  enum : int { C_PIXEL, C_HITSEED,  // x | y << 16 ; hit | seed index << 26
+               C_FIX,               // npend | (o - 1) << 2 | (i - 8) << 3 | (fix + 2) << 5
+               C_BV,                // the sample's radiance sums so far, r | g << 10 | b << 20: two exits of at most 255 each per channel
+               C_ATTEN, C_ER, C_EG, C_EB, C_COLOR, C_FIELDS };
+  __shared__ uint32_t cold[C_FIELDS][2][256];
+  __syncthreads();
+  uint32_t cs = 0u;  // which of the lane's two event-state slots belongs to `cur`
+#define COLD(f) cold[f][cs][threadIdx.x]
+  const uint32_t n_hits = a.n_hits_on_device ? a.counters[0] : a.n_hits;
+  const uint32_t n_chunks = (n_hits + 63u) >> 6;
+  const unsigned lane = lane_id();
+  unsigned home_queue = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;
+  if (a.unit_affinity == 1) home_queue = (blockIdx.x * 4u + (threadIdx.x >> 6)) & 7u;
+  if (a.unit_affinity == 2) home_queue = 0u;
+  unsigned queue_dry = 0u;
+  // cur: the ray the step loop and the event phase work on; alt: the lane's other ray
+  Ray ray{{0, 0, 0}, {0, 0, 0}}, aray{{0, 0, 0}, {0, 0, 0}};
+  int st = ST_IDLE, sd = 0, steps_left = 0;
+  uint32_t ameta = (uint32_t)ST_IDLE;  // alt's st | sd << 8 | steps_left << 16
+  const int cert_min_lanes = a.cert_min_lanes;
+  const int cert_at = a.cert_min_step != 0 ? a.cert_min_step : kCertNever;
+  bool exhausted = false;
+#ifdef CLVR_BOUNCE_STATS
+  uint32_t st_step_iters = 0, st_step_lanes = 0, st_event_phases = 0, st_event_lanes = 0, st_refills = 0, st_refill_lanes = 0, st_swaps = 0;
+#endif
+  auto swap_rays = [&](bool doit) {
+    if (doit) {
+      float t;
+      t = ray.origin.x; ray.origin.x = aray.origin.x; aray.origin.x = t;
+      t = ray.origin.y; ray.origin.y = aray.origin.y; aray.origin.y = t;
+      t = ray.origin.z; ray.origin.z = aray.origin.z; aray.origin.z = t;
+      t = ray.direction.x; ray.direction.x = aray.direction.x; aray.direction.x = t;
+      t = ray.direction.y; ray.direction.y = aray.direction.y; aray.direction.y = t;
+      t = ray.direction.z; ray.direction.z = aray.direction.z; aray.direction.z = t;
+      const uint32_t m = (uint32_t)st | ((uint32_t)sd << 8) | ((uint32_t)steps_left << 16);
+      st = (int)(ameta & 255u); sd = (int)((ameta >> 8) & 255u); steps_left = (int)(ameta >> 16);
+      ameta = m;
+      cs ^= 1u;
+    }
+  };
+
+  for (;;) {
+    // ---- present what the event phase and the refill can work on in `cur` ------------------------------
+    bool will_refill;
+    {
+      const int ast = (int)(ameta & 255u);
+      const bool cur_busy = st == ST_MARCH || st == ST_CERT, alt_ev = ast >= ST_EVENT, alt_idle = ast == ST_IDLE;
+      will_refill = !exhausted && (uint32_t)__popcll(__ballot(st == ST_IDLE || alt_idle)) >= (uint32_t)a.refill_min_lanes;
+      swap_rays((cur_busy && alt_ev) || (st == ST_IDLE && alt_ev) || (will_refill && cur_busy && alt_idle));
+#ifdef CLVR_BOUNCE_STATS
+      st_swaps += 1;
+#endif
+    }
+    // ---- refill: lanes whose cur is idle pull consecutive items of the unit queues (k_bounce's scheme) ---
+    const unsigned long long idle_mask = __ballot(st == ST_IDLE);
+    const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+    if (will_refill && n_idle != 0u) {
+      const uint32_t NQ = (uint32_t)a.unit_queues, S = (uint32_t)a.n_seeds, G = (uint32_t)a.unit_group;
+      const uint32_t KB = (uint32_t)a.unit_block_log2, n_blocks = (n_chunks + (1u << KB) - 1u) >> KB;
+      uint32_t base = 0u, count = 0u, q_sel = 0u;
+      if (lane == 0u) {
+        for (uint32_t tries = 0; tries < NQ && count == 0u; ++tries) {
+          const uint32_t q = (home_queue + tries) % NQ;
+          const uint32_t blocks_q = (n_blocks + NQ - 1u - q) / NQ;
+          const uint32_t chunks_q = blocks_q << KB;
+          if (chunks_q == 0u || ((queue_dry >> q) & 1u)) continue;
+          const uint32_t total = chunks_q * S * 64u;
+          const uint32_t p = atomicAdd(&a.counters[32u * (q + 1u)], n_idle);
+          if (p + n_idle >= total) queue_dry |= 1u << q;
+          if (p < total) {
+            base = p;
+            count = min(n_idle, total - p);
+            q_sel = q;
+          }
+        }
+      }
+      base = __shfl(base, 0);
+      count = __shfl(count, 0);
+      q_sel = __shfl(q_sel, 0);
+#ifdef CLVR_BOUNCE_STATS
+      st_refills += 1; st_refill_lanes += count;
+#endif
+      if (count == 0u) {
+        exhausted = true;
+      } else if (st == ST_IDLE) {
+        const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+        if (rank < count) {
+          const uint32_t item = base + rank, p = item >> 6;
+          const uint32_t chunks_q = ((n_blocks + NQ - 1u - q_sel) / NQ) << KB;
+          uint32_t r, c_in;
+          const uint32_t g = udivmod24(p, G * S, r);
+          const uint32_t in_group = min(G, chunks_q - g * G);
+          const uint32_t s = udivmod24(r, in_group, c_in), ch = g * G + c_in;
+          const uint32_t chunk = ((q_sel + NQ * (ch >> KB)) << KB) + (ch & ((1u << KB) - 1u));
+          const uint32_t h = chunk * 64u + (item & 63u);
+          if (h < n_hits) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(&a.hits[h]);
+            const uint4 q2 = src[2], q3 = src[3];
+            const uint32_t color = q2.y;
+            const int64_t entry = (int64_t)(((uint64_t)q2.w << 32) | (uint64_t)q2.z);
+            bool granted = true;
+            if (MODE == CLWH_ACCUM_VOXEL_CACHE)
+              granted = a.grants ? s < a.grants[h] : (entry >= 0 && cache_take_token(a.cache, entry, 256u));
+            if (granted) {
+              COLD(C_PIXEL) = q3.x;
+              COLD(C_HITSEED) = h | (s << 26);
+              COLD(C_FIX) = (uint32_t)(-1 + 2) << 5;  // no fix-up record, o = 1, i = 8, nothing pending
+              COLD(C_BV) = 0u;
+              COLD(C_ATTEN) = 0u;
+              COLD(C_ER) = __float_as_uint(div255[color & 255u]);
+              COLD(C_EG) = __float_as_uint(div255[(color >> 8) & 255u]);
+              COLD(C_EB) = __float_as_uint(div255[(color >> 16) & 255u]);
+              COLD(C_COLOR) = color;
+              st = ST_EVENT + EV_START;
+            } else if (a.contrib_out) {
+              uint32_t *q = a.contrib_out + ((size_t)(q3.x >> 16) * (size_t)a.launch_w + (q3.x & 0xFFFFu)) * 4;
+              q[0] = 0u; q[1] = 0u; q[2] = 0u; q[3] = 0u;
+            }
+          }
+        }
+      }
+    }
+    if (__ballot(st != ST_IDLE || (ameta & 255u) != (uint32_t)ST_IDLE) == 0ull) {
+#ifdef CLVR_BOUNCE_STATS
+      if (exhausted && lane == 0u) {
+        atomicAdd(&a.counters[8], st_step_iters); atomicAdd(&a.counters[9], st_step_lanes);
+        atomicAdd(&a.counters[10], st_event_phases); atomicAdd(&a.counters[11], st_event_lanes);
+        atomicAdd(&a.counters[12], st_refills); atomicAdd(&a.counters[13], st_refill_lanes);
+        atomicAdd(&a.counters[21], st_swaps);
+      }
+#endif
+      if (exhausted) break;
+      continue;
+    }
+
+    // ---- event phase on cur: k_bounce's, with the event-only state read from / written to the ray's LDS slot ----
+#ifdef CLVR_BOUNCE_STATS
+    if (__ballot(st >= ST_EVENT) != 0ull) { st_event_phases += 1; st_event_lanes += (uint32_t)__popcll(__ballot(st >= ST_EVENT)); }
+#endif
+    if (st >= ST_EVENT) {
+      int ev = st - ST_EVENT;
+      uint32_t fixw = COLD(C_FIX);
+      int o = (int)((fixw >> 2) & 1u) + 1, i = (int)((fixw >> 3) & 3u) + 8;
+      uint32_t color = COLD(C_COLOR);
+      if (ev == EV_CHECK) {
+        for (;;) {
+          if (exited_volume(vol, ray.origin)) { ev = EV_EXIT; break; }
+          int next_sd;
+          bool pending = false;
+          if (classify_step<USE_GRAD, SMALL, true>(vol, a.tf, ray.origin, color, next_sd, &pending)) {
+            ev = pending ? EV_HIT_COLOR_PENDING : EV_HIT;
+            break;
+          }
+          if (steps_left == 0) { ev = EV_NONE; break; }
+          ray.origin = ray.origin + ray.direction * fmaxf((float)next_sd, 0.5f);
+          --steps_left;
+        }
+      }
+      bool start_path = (ev == EV_START);
+      bool bounce = false, from_hit = false;
+      f3 bn{0, 0, 0}, bstart{0, 0, 0};
+      int bseed = 0;
+      const uint32_t hitseed = COLD(C_HITSEED);
+      const uint32_t h = hitseed & 0x03FFFFFFu;
+
+      if (ev == EV_EXIT) {
+        const float factor = i == 8 ? 8.0f / 8.0f : (i == 9 ? 8.0f / 9.0f : (i == 10 ? 8.0f / 10.0f : 8.0f / (float)i));
+        const float atten = __uint_as_float(COLD(C_ATTEN));
+        const float p_r = atten * __uint_as_float(COLD(C_ER)), p_g = atten * __uint_as_float(COLD(C_EG)), p_b = atten * __uint_as_float(COLD(C_EB));
+        uint32_t light = 0u;
+        int fix = (int)(fixw >> 5) - 2, npend = (int)(fixw & 3u);
+        const bool certain = (fix == -1) && sample_environment_map_fast(a.env, a.env_w, a.env_h, ray.direction, light);
+        const uint32_t bv = COLD(C_BV);
+        if (certain) {
+          // uint += float: promote, add, truncate back
+          const uint32_t br = f2u((float)(bv & 1023u) + p_r * (float)(light & 255u) * factor / 1.0f);
+          const uint32_t bg = f2u((float)((bv >> 10) & 1023u) + p_g * (float)((light >> 8) & 255u) * factor / 1.0f);
+          const uint32_t bb = f2u((float)(bv >> 20) + p_b * (float)((light >> 16) & 255u) * factor / 1.0f);
+          COLD(C_BV) = br | (bg << 10) | (bb << 20);
+        } else {
+          if (fix == -1) {
+            const uint32_t slot = atomicAdd(&a.counters[2], 1u);
+            if (slot < a.fixup_capacity) {
+              fix = (int)slot;
+              uint32_t *rec = a.fixups + (size_t)slot * kFixupDwords;
+              const HitRec &hr = a.hits[h];
+              rec[0] = h;
+              rec[1] = (uint32_t)hr.entry_lo;
+              rec[2] = (uint32_t)hr.entry_hi;
+              rec[3] = COLD(C_PIXEL);
+              rec[4] = bv & 1023u; rec[5] = (bv >> 10) & 1023u; rec[6] = bv >> 20;
+            } else {
+              a.sticky_flags[0] = 1u;
+              fix = -2;
+            }
+          }
+          if (fix >= 0) {
+            uint32_t *e = a.fixups + (size_t)fix * kFixupDwords + 8 + 7 * npend;
+            e[0] = __float_as_uint(p_r); e[1] = __float_as_uint(p_g); e[2] = __float_as_uint(p_b);
+            e[3] = __float_as_uint(factor);
+            e[4] = __float_as_uint(ray.direction.x); e[5] = __float_as_uint(ray.direction.y);
+            e[6] = __float_as_uint(ray.direction.z);
+            npend += 1;
+          }
+          fixw = (fixw & 0x1Cu) | (uint32_t)npend | ((uint32_t)(fix + 2) << 5);
+        }
+        o += 1;
+        start_path = true;
+      } else if (ev == EV_HIT || ev == EV_HIT_COLOR_PENDING) {
+        bn = -normalize3(hit_gradient_and_color<SMALL>(vol, a.tf, ray.origin, ev == EV_HIT_COLOR_PENDING, color));
+        bstart = ray.origin + ray.direction;
+        bseed = o + i;
+        bounce = true;
+        from_hit = true;
+        i += 1;
+        if (i > 10) {
+          COLD(C_ER) = __float_as_uint(__uint_as_float(COLD(C_ER)) * div255[color & 255u]);
+          COLD(C_EG) = __float_as_uint(__uint_as_float(COLD(C_EG)) * div255[(color >> 8) & 255u]);
+          COLD(C_EB) = __float_as_uint(__uint_as_float(COLD(C_EB)) * div255[(color >> 16) & 255u]);
+          bounce = false;
+          o += 1;
+          start_path = true;
+        }
+      } else if (ev == EV_NONE) {
+        i += 1;
+        if (i > 10) {
+          o += 1;
+          start_path = true;
+        }
+      }
+
+      if (start_path) {
+        if (o > 2) {
+          const int fix = (int)(fixw >> 5) - 2;
+          if (fix == -1) {
+            const uint32_t bv = COLD(C_BV), pixel = COLD(C_PIXEL);
+            int64_t entry = 0;
+            if (MODE == CLWH_ACCUM_VOXEL_CACHE && a.grants == nullptr) {
+              const HitRec &hr = a.hits[h];
+              entry = (int64_t)(((uint64_t)(uint32_t)hr.entry_hi << 32) | (uint64_t)(uint32_t)hr.entry_lo);
+            }
+            finish_item<MODE>(a, entry, h, pixel & 0xFFFFu, pixel >> 16, bv & 1023u, (bv >> 10) & 1023u, bv >> 20);
+          } else if (fix >= 0) {
+            a.fixups[(size_t)fix * kFixupDwords + 7] = fixw & 3u;  // k_env_fixup finishes it
+          }
+          st = ST_IDLE;
+        } else {
+          // ray_marching.cl:48: bounce from the primary hit around the primary normal (re-read from the hit's record)
+          const uint4 *src = reinterpret_cast<const uint4 *>(&a.hits[h]);
+          const uint4 q0 = src[0], q1 = src[1];
+          const uint32_t nz = reinterpret_cast<const uint32_t *>(&a.hits[h])[8];
+          const f3 hit_origin = f3{__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)};
+          const f3 hit_direction = f3{__uint_as_float(q0.w), __uint_as_float(q1.x), __uint_as_float(q1.y)};
+          bn = f3{__uint_as_float(q1.z), __uint_as_float(q1.w), __uint_as_float(nz)};
+          bstart = hit_origin + hit_direction;
+          bseed = o;
+          bounce = true;
+          from_hit = false;
+        }
+      }
+
+      if (bounce) {
+        const float roughness = div255[color >> 24];
+        const uint32_t pixel = COLD(C_PIXEL);
+        Ray nr;
+        nr.direction = hemisphere_reflective(pixel & 0xFFFFu, pixel >> 16, bn, s_seeds[hitseed >> 26] + bseed, roughness);
+        nr.origin = bstart + bn * 2.0f;
+        const float d = fabsf(dot3(nr.direction, bn));
+        if (from_hit) {
+          COLD(C_ATTEN) = __float_as_uint(__uint_as_float(COLD(C_ATTEN)) * d);
+          COLD(C_ER) = __float_as_uint(__uint_as_float(COLD(C_ER)) * div255[color & 255u]);
+          COLD(C_EG) = __float_as_uint(__uint_as_float(COLD(C_EG)) * div255[(color >> 8) & 255u]);
+          COLD(C_EB) = __float_as_uint(__uint_as_float(COLD(C_EB)) * div255[(color >> 16) & 255u]);
+        } else {
+          COLD(C_ATTEN) = __float_as_uint(d);
+          i = 8;
+        }
+        ray = nr;
+      }
+
+      if (st >= ST_EVENT) {
+        sd = (int)(vol.template step_i<SMALL>(f2i(ray.origin.x), f2i(ray.origin.y), f2i(ray.origin.z)) & 0x7Fu);
+        steps_left = 70;
+        st = ST_MARCH;
+        COLD(C_FIX) = (fixw & ~0x1Cu) | ((uint32_t)(o - 1) << 2) | ((uint32_t)(i - 8) << 3);
+        COLD(C_COLOR) = color;
+      }
+    }
+
+    // ---- two rounds of the step loop on cur; between them lanes whose cur is parked swap in a marching alt ----
+    for (int round = 0; round < 2; ++round) {
+      if (round == 1) {
+        const int ast = (int)(ameta & 255u);
+        swap_rays(!(st == ST_MARCH || st == ST_CERT) && (ast == ST_MARCH || ast == ST_CERT));
+#ifdef CLVR_BOUNCE_STATS
+        st_swaps += 1;
+#endif
+      }
+      if (__ballot(st == ST_MARCH || st == ST_CERT) == 0ull) continue;
+      do {
+#ifdef CLVR_BOUNCE_STATS
+        st_step_iters += 1; st_step_lanes += (uint32_t)__popcll(__ballot(st == ST_MARCH));
+#endif
+        if (st == ST_MARCH) {
+          ray.origin = ray.origin + ray.direction * fmaxf((float)sd, 0.5f);
+          --steps_left;
+          if (!USE_GRAD) {
+            const bool has_voxel = __float_as_uint(ray.origin.x) < __float_as_uint((float)a.X) &&
+                                   __float_as_uint(ray.origin.y) < __float_as_uint((float)a.Y) &&
+                                   __float_as_uint(ray.origin.z) < __float_as_uint((float)a.Z);
+            if (has_voxel) {
+              const unsigned q = vol.template step_marched<SMALL>(ray.origin.x, ray.origin.y, ray.origin.z);
+              sd = (int)(q & 0x7Fu);
+              if (q & 0x80u) st = ST_EVENT + EV_HIT_COLOR_PENDING;
+              else if (steps_left == 0) st = ST_EVENT + EV_NONE;
+              else if (sd >= cert_at) st = ST_CERT;
+            } else {
+              st = ST_EVENT + EV_CHECK;
+            }
+          } else if (exited_volume(vol, ray.origin)) {
+            st = ST_EVENT + EV_EXIT;
+          } else {
+            int next_sd;
+            bool pending = false;
+            uint32_t c = COLD(C_COLOR);
+            const bool is_hit = classify_step<USE_GRAD, SMALL, true>(vol, a.tf, ray.origin, c, next_sd, &pending);
+            if (is_hit) {
+              if (!pending) COLD(C_COLOR) = c;  // the literal route's rule colour
+              st = ST_EVENT + (pending ? EV_HIT_COLOR_PENDING : EV_HIT);
+            } else if (steps_left == 0) {
+              st = ST_EVENT + EV_NONE;
+            } else {
+              sd = next_sd;
+              if (sd >= cert_at) st = ST_CERT;
+            }
+          }
+        }
+        const int n_cert = __popcll(__ballot(st == ST_CERT));
+        if (n_cert != 0 && (n_cert >= cert_min_lanes || __popcll(__ballot(st == ST_MARCH)) < a.step_min_lanes)) {
+          if (st == ST_CERT) st = certify_exit(a, ray.origin, ray.direction, steps_left) ? ST_EVENT + EV_EXIT : ST_MARCH;
+        }
+      } while (__popcll(__ballot(st == ST_MARCH)) >= a.step_min_lanes);
+      // lanes still waiting for a certificate when the loop ends: look it up now (the loop's own condition does so only while it runs)
+      if (__ballot(st == ST_CERT) != 0ull) {
+        if (st == ST_CERT) st = certify_exit(a, ray.origin, ray.direction, steps_left) ? ST_EVENT + EV_EXIT : ST_MARCH;
+      }
+    }
+  }
+#undef COLD
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_env_fixup: one lane per fix-up record; exact lookups, then the reference's arithmetic in its order
 template <int MODE>
 __global__ __launch_bounds__(256) void k_env_fixup(const RenderArgs a) {
@@ -1142,9 +1522,15 @@ hipError_t launch_bounce(const RenderArgs &a_in, hipStream_t s) {
   const bool small = (uint64_t)a.NBX * (uint64_t)a.NBY * (uint64_t)((a.Z + 7) / 8) < (1ull << 23) &&
                      a.X + a.Y + a.Z <= VolumePacked::kPartsMaxEntries;
   const size_t lds_parts_bytes = small ? (size_t)(a.X + a.Y + a.Z) * sizeof(uint32_t) : 0u;
+  // CLWH_TUNE_BOUNCE_RAYS=2: long launches run k_bounce2 (two rays per lane; hit index and seed index share a dword: 2^26 hits)
+  const bool two_rays = a.bounce_rays == 2 && long_launch && a.n_hits < (1u << 26) && kBounceThreads == 256;
+  if (two_rays) a.fixup_capacity = std::min<uint32_t>(a.fixup_capacity, (1u << 27) - 4u);
 #define CLVR_LAUNCH_BOUNCE(G, M)                                                                    \
   do {                                                                                              \
-    if (small) hipLaunchKernelGGL((k_bounce<G, M, true>), grid, block, lds_parts_bytes, s, a);     \
+    if (two_rays) {                                                                                 \
+      if (small) hipLaunchKernelGGL((k_bounce2<G, M, true>), grid, block, lds_parts_bytes, s, a);  \
+      else hipLaunchKernelGGL((k_bounce2<G, M, false>), grid, block, 0, s, a);                     \
+    } else if (small) hipLaunchKernelGGL((k_bounce<G, M, true>), grid, block, lds_parts_bytes, s, a); \
     else hipLaunchKernelGGL((k_bounce<G, M, false>), grid, block, 0, s, a);                        \
   } while (0)
   if (a.mode == CLWH_ACCUM_VOXEL_CACHE) {

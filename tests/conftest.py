@@ -123,6 +123,15 @@ def _ctx_with_env(env):
 
 
 @pytest.fixture(scope="session")
+def gpu_ctx_two_rays():
+    """every launch scheduled like a long one AND run by k_bounce2 (two rays per lane, CLWH_TUNE_BOUNCE_RAYS=2: the round-3
+    lane-utilisation experiment, csrc/render_kernels.hip)"""
+    ctx = _ctx_with_env({"CLWH_TUNE_LONG_LAUNCH": "1", "CLWH_TUNE_BOUNCE_RAYS": "2"})
+    yield ctx
+    ctx.destroy()
+
+
+@pytest.fixture(scope="session")
 def gpu_ctx_sdf_front():
     """a context whose clwh_sdf_build runs the byte front (one launch per layer) instead of the bit-parallel build"""
     ctx = _ctx_with_env({"CLWH_TUNE_SDF": "front"})
