@@ -203,6 +203,9 @@ struct SdfBitArgs {
   int32_t X, Y, Z, WP;
   int32_t BX, BY, BZ, core_z;  // blocks of 64 x 48 x core_z voxels (sdfbit_block_grid)
   int32_t r0, steps;       // steps <= 8
+  uint32_t *planes;        // seven bit planes of the layer index (8 launch + layer-in-launch + 1, 1..127) of every voxel a layer reached,
+                           // each tiled like the reached sets; OR-ed in by the launches, expanded to bytes ONCE by k_sdfbit_expand
+  size_t plane_words;      // words per plane
   uint32_t *list;          // blocks that can change in this launch (k_sdfbit_list)
   uint32_t *list_count;    // their number; list_head: the persistent grid's queue position
   uint32_t *list_head;
@@ -212,7 +215,8 @@ struct SdfBitArgs {
 };
 void sdfbit_block_grid(int X, int Y, int Z, int waves, int32_t *BX, int32_t *BY, int32_t *BZ, int32_t *core_z);  // blocks of 64 x 48 x (4 waves - 16) voxels
 hipError_t launch_sdfbit_events(const SdfArgs &a, uint32_t *ev, int32_t WP, hipStream_t s);
-hipError_t launch_sdfbit_seed_init(const SdfBitArgs &a, int32_t max_iterations, hipStream_t s);  // seeds into a.r_out, base image into a.sdf
+hipError_t launch_sdfbit_seed(const SdfBitArgs &a, hipStream_t s);                                // seeds into a.r_out
+hipError_t launch_sdfbit_expand(const SdfBitArgs &a, const uint32_t *reached, int32_t max_iterations, hipStream_t s);  // bit planes + final reached set -> a.sdf
 hipError_t launch_sdfbit_state(const SdfBitArgs &a, hipStream_t s);                              // block states of a.r_in
 hipError_t launch_sdfbit_layers(const SdfBitArgs &a, int waves, unsigned grid_blocks, hipStream_t s);
 

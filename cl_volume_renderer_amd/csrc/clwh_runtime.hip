@@ -1180,11 +1180,14 @@ static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settl
   // blocks, per-launch {count, head}, the regions' states and wake stamps
   const size_t tiled = n_blocks * (size_t)(2 * 48 * a.core_z);
   const size_t small = n_blocks + 2 * (size_t)(n_launches + 1);
-  const size_t scratch_words = words + 2 * tiled + small;
+  const size_t scratch_words = words + 2 * tiled + small + 7 * tiled;  // ... and the seven bit planes of the layer index
   int rc = grow(ctx, (void **)&ctx->sdf_bits, &ctx->sdf_bits_bytes, scratch_words * sizeof(uint32_t) + 2 * n_blocks);
   if (rc != CLWH_OK) return rc;
   uint32_t *ev = ctx->sdf_bits, *reached[2] = {ctx->sdf_bits + words, ctx->sdf_bits + words + tiled};  // words and tiled are even: 8-byte aligned
   uint32_t *list = ctx->sdf_bits + words + 2 * tiled, *queue = list + n_blocks;
+  a.planes = ctx->sdf_bits + words + 2 * tiled + small;
+  a.plane_words = tiled;
+  HIP_TRY(hipMemsetAsync(a.planes, 0, 7 * tiled * sizeof(uint32_t), ctx->stream));
   a.sdf = b.ping;
   a.ev = ev;
   a.list = list;
@@ -1196,7 +1199,7 @@ static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settl
   HIP_TRY(hipMemsetAsync(a.wake, 0, n_blocks, ctx->stream));
   HIP_TRY(launch_sdfbit_events(b, ev, a.WP, ctx->stream));
   a.r_out = reached[0];
-  HIP_TRY(launch_sdfbit_seed_init(a, b.max_iterations, ctx->stream));
+  HIP_TRY(launch_sdfbit_seed(a, ctx->stream));
   a.r_in = reached[0];
   HIP_TRY(launch_sdfbit_state(a, ctx->stream));
 #ifdef CLVR_SDFBIT_TIMING
@@ -1216,6 +1219,8 @@ static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settl
     a.list_head = queue + 2 * t + 1;
     HIP_TRY(launch_sdfbit_layers(a, waves, (unsigned)ctx->tune_sdfbit_grid * (waves == 16 ? 1u : 2u) / 2u, ctx->stream));
   }
+  // the values, once: the reached set after the last launch is the one it wrote (regions complete earlier are complete in both)
+  HIP_TRY(launch_sdfbit_expand(a, reached[t & 1], b.max_iterations, ctx->stream));
   HIP_TRY(hipMemcpyAsync(settled.data(), ctx->sdf_counters, kSlots * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
 #ifdef CLVR_SDFBIT_TIMING

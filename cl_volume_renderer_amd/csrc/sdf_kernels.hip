@@ -570,39 +570,71 @@ __global__ __launch_bounds__(256) void k_sdfbit_seed(const uint32_t *__restrict_
   if (differs) presence[0] = 1;  // non-zero marker, plain store (see k_sdf_base_front)
 }
 
-// base image from the two bit sets: +-1 at a seed, +-max_iterations elsewhere
-__global__ __launch_bounds__(256) void k_sdfbit_init(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ r0, int8_t *__restrict__ sdf,
-                                                      int32_t X, int32_t Y, int32_t Z, int32_t WP, int32_t max_iterations, SdfBitTiles tiles) {
+// The values, once: bit planes of the layer index + the final reached set + the event bits -> one signed byte per voxel.
+// A seed (reached, index 0) holds +-1, a voxel reached by layer `index` holds +-(index + 1), an unreached one +-max_iterations
+// (create_base_image's values for the first and the last, signed_distance_field.cl:40-53; the sign is the event class).
+__device__ __forceinline__ uint32_t sdfbit_index_bits(const uint32_t *__restrict__ planes, size_t plane_words, size_t word, int p) {
+  return planes[(size_t)p * plane_words + word];
+}
+__global__ __launch_bounds__(256) void k_sdfbit_expand(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ reached, const uint32_t *__restrict__ planes,
+                                                        size_t plane_words, int8_t *__restrict__ sdf, int32_t X, int32_t Y, int32_t Z, int32_t WP,
+                                                        int32_t max_iterations, SdfBitTiles tiles) {
   const int x = blockIdx.x * 256 + threadIdx.x;
   const int y = blockIdx.y, z = blockIdx.z;
   if (x >= X) return;
-  const size_t roww = ((size_t)z * Y + y) * (size_t)WP + (size_t)(x >> 5);
-  const uint32_t e = (ev[roww] >> (x & 31)) & 1u, s = (r0[tiles.word(x >> 5, y, z)] >> (x & 31)) & 1u;
-  const int val = s ? 1 : max_iterations;
+  const size_t roww = ((size_t)z * Y + y) * (size_t)WP + (size_t)(x >> 5), tw = tiles.word(x >> 5, y, z);
+  const uint32_t sh = (uint32_t)(x & 31);
+  const uint32_t e = (ev[roww] >> sh) & 1u, r = (reached[tw] >> sh) & 1u;
+  uint32_t index = 0u;
+  if (r) {
+#pragma unroll
+    for (int p = 0; p < 7; ++p) index |= ((sdfbit_index_bits(planes, plane_words, tw, p) >> sh) & 1u) << p;
+  }
+  const int val = r ? (int)index + 1 : max_iterations;
   sdf[((size_t)z * Y + y) * (size_t)X + (size_t)x] = (int8_t)(e ? -val : val);
 }
 
-// the same, sixteen voxels (one 16-byte store) per lane: rows of a multiple of 16 voxels, max_iterations >= 1
-__global__ __launch_bounds__(256) void k_sdfbit_init16(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ r0, int8_t *__restrict__ sdf,
-                                                        int32_t X, int32_t Y, int32_t Z, int32_t WP, int32_t max_iterations, SdfBitTiles tiles) {
+// the same, sixteen voxels (one 16-byte store) per lane: rows of a multiple of 16 voxels
+__global__ __launch_bounds__(256) void k_sdfbit_expand16(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ reached, const uint32_t *__restrict__ planes,
+                                                          size_t plane_words, int8_t *__restrict__ sdf, int32_t X, int32_t Y, int32_t Z, int32_t WP,
+                                                          int32_t max_iterations, SdfBitTiles tiles) {
   size_t row;
   uint32_t unit;
   if (!sdfbit_row_unit((uint32_t)(X / 16), (size_t)Y * (size_t)Z, row, unit)) return;
-  const uint32_t b1 = 0x01010101u, mb = (uint32_t)max_iterations * b1, dm = (uint32_t)(max_iterations - 1);
+  const uint32_t b1 = 0x01010101u;
   const int x0 = (int)unit * 16;
-  const size_t wi = row * (size_t)WP + (size_t)(x0 >> 5);
   const int z = (int)(row / (size_t)Y), y = (int)(row - (size_t)z * (size_t)Y);
-  const uint32_t e16 = (ev[wi] >> (x0 & 31)) & 0xFFFFu, s16 = (r0[tiles.word(x0 >> 5, y, z)] >> (x0 & 31)) & 0xFFFFu;
+  const size_t tw = tiles.word(x0 >> 5, y, z);
+  const uint32_t sh = (uint32_t)(x0 & 31);
+  const uint32_t e16 = (ev[row * (size_t)WP + (size_t)(x0 >> 5)] >> sh) & 0xFFFFu, r16 = (reached[tw] >> sh) & 0xFFFFu;
+  uint32_t p16[7];
+#pragma unroll
+  for (int p = 0; p < 7; ++p) p16[p] = 0u;
+  if (r16 != 0u) {  // nothing reached here (the far field beyond 126 layers, empty volumes): no plane is read
+#pragma unroll
+    for (int p = 0; p < 7; ++p) p16[p] = (sdfbit_index_bits(planes, plane_words, tw, p) >> sh) & 0xFFFFu;
+  }
   uint32_t out[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    // four bits -> four bytes of 0 / 1
-    const uint32_t sb = (((s16 >> (4 * q)) & 0xFu) * 0x00204081u) & b1, eb = (((e16 >> (4 * q)) & 0xFu) * 0x00204081u) & b1;
-    const uint32_t val = mb - sb * dm;               // per byte: seed ? 1 : max_iterations (1..127, no borrow between bytes)
-    const uint32_t neg = eb * 0xFFu;                  // 0xFF where the voxel is an event
-    out[q] = (val ^ neg) + eb;                        // two's complement per byte: 255 - v + 1 <= 255, no carry
+    auto spread = [&](uint32_t bits16) { return __umul24((bits16 >> (4 * q)) & 0xFu, 0x204081u) & b1; };  // four bits -> the low bit of four bytes
+    auto bytes_ff = [](uint32_t ones) { return (ones << 8) - ones; };                                        // 0 / 1 per byte -> 0x00 / 0xFF
+    uint32_t idx = 0u;
+#pragma unroll
+    for (int p = 0; p < 7; ++p) idx += spread(p16[p]) << p;                                                  // <= 127 per byte
+    const uint32_t rb = bytes_ff(spread(r16)), eb = spread(e16);
+    const uint32_t val = ((idx + b1) & rb) | (((uint32_t)max_iterations * b1) & ~rb);                        // reached: index + 1 (<= 128 - 1); else max
+    out[q] = (val ^ bytes_ff(eb)) + eb;                                                                      // two's complement per byte where the voxel is an event
   }
   *reinterpret_cast<uint4 *>(sdf + row * (size_t)X + (size_t)x0) = uint4{out[0], out[1], out[2], out[3]};
+}
+
+// A barrier of k_sdfbit_layers: LDS only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores and atomics (a release fence
+// at workgroup scope) -- here the write-back of a region (bit rows, plane ORs, state bytes), which nobody reads before the next launch; with
+// it, the first barrier of a block's NEXT region stalled until those partial-line stores had been acknowledged.  LDS operations are
+// still complete (lgkmcnt(0)) before the wave arrives, and the compiler may not move memory operations across it.
+__device__ __forceinline__ void sdfbit_lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 constexpr int kBitCoreY = 48, kBitHalo = 8, kBitRows = 4;  // a wave = 64 rows along y (48 core + 2 x 8 halo) x 4 rows along z
@@ -731,7 +763,7 @@ __device__ __forceinline__ void sdfbit_steps(SdfBitLane &L, uint4 (*s_x)[NW][2][
     uint4 *xbuf = &s_x[k & 1][0][0][0];
     xbuf[(strip * 2 + 0) * 64 + lane] = uint4{v[0][0], v[0][1], v[0][2], v[0][3]};
     xbuf[(strip * 2 + 1) * 64 + lane] = uint4{v[kBitRows - 1][0], v[kBitRows - 1][1], v[kBitRows - 1][2], v[kBitRows - 1][3]};
-    __syncthreads();
+    sdfbit_lds_barrier();
     uint4 below = uint4{0u, 0u, 0u, 0u}, above = uint4{0u, 0u, 0u, 0u};
     if (strip > 0) below = xbuf[((strip - 1) * 2 + 1) * 64 + lane];
     if (strip < NW - 1) above = xbuf[((strip + 1) * 2 + 0) * 64 + lane];
@@ -791,14 +823,14 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
   const bool core_lane = lane >= (unsigned)kBitHalo && lane < (unsigned)(kBitHalo + kBitCoreY);
   const bool core_strip = strip >= kBitHalo / kBitRows && strip < NW - kBitHalo / kBitRows;
   for (uint32_t round = 0u;; ++round) {
-    __syncthreads();  // the previous region's flags and exchange rows are no longer read
+    sdfbit_lds_barrier();  // the previous region's flags and exchange rows are no longer read
     if (tid == 0u) {
       // dynamic: regions differ in cost (complete ones only copy); a static round-robin over the list measured 1.84 ms against 1.60
       s_entry = round == 0u ? blockIdx.x : gridDim.x + atomicAdd(a.list_head, 1u);
       s_all = 1u; s_any = 0u; s_steps = 0u; s_orx[0] = 0u; s_orx[1] = 0u;
       s_box[0] = 255; s_box[1] = -1; s_box[2] = 255; s_box[3] = -1;
     }
-    __syncthreads();
+    sdfbit_lds_barrier();
 #ifdef CLVR_SDFBIT_TIMING
     const bool probe = tid == 64u * 2u + 8u;
     const unsigned long long tq0 = wall_clock64();
@@ -914,52 +946,32 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
     if (!all) s_all = 0u;
     if (L.step_mask) atomicOr(&s_steps, L.step_mask);
 
-    // values: every lane rewrites the 64 bytes of its own rows that gained voxels (the block owns its core rows, so a plain
-    // read-modify-write is race-free): four bits -> four bytes with shifts, the layer bits summed per byte.  The first
-    // version sent each row through the wave (one row per iteration, lane = voxel): 1 to 28 us per region.
+    // values: NOT written here.  Round 2 let every lane rewrite the 64 bytes of its rows that gained voxels -- a load and a store of
+    // 16 bytes per lane at a 512-byte stride, partial lines whose completion the next barrier waited for: two thirds of a region's
+    // time.  Now the layer in which a voxel was reached goes into seven bit planes (tiled like the reached sets: a wave's rows are
+    // contiguous) with fire-and-forget atomic ORs -- a voxel is reached exactly once, so the launches never write the same bit -- and
+    // k_sdfbit_expand turns planes + final reached set + event bits into bytes ONCE, after the last launch, with full-line stores.
+    // layer index = r0 + k + 1 (1..127; r0 = 8 x launch, k the layer inside the launch as recorded bit-sliced in rec_b0..2)
     if (core_strip && core_lane && y_in) {
-      const uint32_t b1 = 0x01010101u, base = (uint32_t)(a.r0 + 2) * b1;  // D = r0 + k + 1 corner moves from the nearest seed, value D + 1
-      const bool wide = (a.X & 15) == 0;  // 16-byte accesses; otherwise byte by byte
+      const uint32_t hi_lo = (uint32_t)a.r0 >> 3, hi_carry = hi_lo + 1u;  // bits 3.. of the index while k + 1 < 8 / when k + 1 == 8
+      // (a plane holds at most 2^28 words: 32-bit word offsets from the plane's own, wave-uniform base keep the addresses out of the VGPRs)
+      const uint32_t lane_word = (uint32_t)b * (uint32_t)kTileWords + (uint32_t)(((kBitRows * strip - kBitHalo) * kBitCoreY + ((int)lane - kBitHalo)) * 2);
 #pragma unroll
       for (int i = 0; i < kBitRows; ++i) {
-        if ((L.rec_any[i][0] | L.rec_any[i][1]) == 0u) continue;  // then the row also lies inside the volume
-        const int gz = zfirst + i;
-        const uint32_t *erow = a.ev + ((size_t)gz * a.Y + gy) * (size_t)a.WP + (size_t)(2 * bx);
-        int8_t *out = a.sdf + ((size_t)gz * a.Y + gy) * (size_t)a.X + (size_t)(bx * 64);
-        // all of the row's loads first (one round trip per row; a branch per 16-voxel group cost sixteen)
-        const uint32_t evw[2] = {erow[0], erow[1]};
-        uint4 old[4];
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          old[h] = uint4{0u, 0u, 0u, 0u};
-          if (wide && bx * 64 + 16 * h < a.X) old[h] = *reinterpret_cast<const uint4 *>(out + 16 * h);
-        }
+        for (int j = 0; j < 2; ++j) {
+          const uint32_t any = L.rec_any[i][j];
+          if (any == 0u) continue;  // (then the row also lies inside the volume)
+          const uint32_t w = lane_word + (uint32_t)(i * kBitCoreY * 2 + j);
+          const uint32_t b0 = L.rec_b0[i][j], b1 = L.rec_b1[i][j], b2 = L.rec_b2[i][j];
+          const uint32_t m7 = b0 & b1 & b2, m = any & ~m7;  // k == 7: the index's low three bits are 0 and bit 3.. carries
+          uint32_t v[7];
+          v[0] = ~b0 & m; v[1] = (b1 ^ b0) & m; v[2] = (b2 ^ (b1 & b0)) & m;  // k + 1, bit-sliced
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {       // 16 voxels
-          const int j = h >> 1, sh = 16 * (h & 1);
-          const uint32_t any16 = (L.rec_any[i][j] >> sh) & 0xFFFFu;
-          if (any16 == 0u) continue;
-          const uint32_t k0 = (L.rec_b0[i][j] >> sh) & 0xFFFFu, k1 = (L.rec_b1[i][j] >> sh) & 0xFFFFu, k2 = (L.rec_b2[i][j] >> sh) & 0xFFFFu,
-                         e16 = (evw[j] >> sh) & 0xFFFFu;
-          uint32_t val[4], msk[4];
+          for (int p = 0; p < 4; ++p) v[3 + p] = (((hi_lo >> p) & 1u) ? m : 0u) | (((hi_carry >> p) & 1u) ? m7 : 0u);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            auto spread = [&](uint32_t bits16) {  // bits 4q .. 4q+3 -> the low bit of four bytes (one 24-bit multiply: no carries between the copies)
-              return __umul24((bits16 >> (4 * q)) & 0xFu, 0x204081u) & b1;
-            };
-            auto bytes_ff = [](uint32_t ones) { return (ones << 8) - ones; };  // 0 / 1 per byte -> 0x00 / 0xFF (= ones * 255 mod 2^32)
-            const uint32_t eb = spread(e16);
-            const uint32_t v = base + spread(k0) + 2u * spread(k1) + 4u * spread(k2);  // <= 126 per byte
-            val[q] = (v ^ bytes_ff(eb)) + eb;                                         // negated where the voxel is an event
-            msk[q] = bytes_ff(spread(any16));
-          }
-          if (wide) {
-            *reinterpret_cast<uint4 *>(out + 16 * h) = uint4{(old[h].x & ~msk[0]) | (val[0] & msk[0]), (old[h].y & ~msk[1]) | (val[1] & msk[1]),
-                                                             (old[h].z & ~msk[2]) | (val[2] & msk[2]), (old[h].w & ~msk[3]) | (val[3] & msk[3])};
-          } else {
-            for (int c = 0; c < 16; ++c)
-              if ((any16 >> c) & 1u) out[16 * h + c] = (int8_t)(val[c >> 2] >> (8 * (c & 3)));
-          }
+          for (int p = 0; p < 7; ++p)
+            if (v[p]) atomicOr(a.planes + (size_t)p * a.plane_words + w, v[p]);
         }
       }
     }
@@ -967,7 +979,7 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
     if (probe) __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long tq4 = wall_clock64();
 #endif
-    __syncthreads();
+    sdfbit_lds_barrier();
 #ifdef CLVR_SDFBIT_TIMING
     if (probe) {
       atomicAdd(&a.timing[0], 1ull); atomicAdd(&a.timing[1], tq1 - tq0); atomicAdd(&a.timing[2], tq2 - tq1); atomicAdd(&a.timing[3], tq3 - tq2);
@@ -1010,16 +1022,22 @@ hipError_t launch_sdfbit_events(const SdfArgs &a, uint32_t *ev, int32_t WP, hipS
   return hipGetLastError();
 }
 
-hipError_t launch_sdfbit_seed_init(const SdfBitArgs &a, int32_t max_iterations, hipStream_t s) {
+hipError_t launch_sdfbit_seed(const SdfBitArgs &a, hipStream_t s) {
   const size_t n_rows = (size_t)a.Y * (size_t)a.Z;
   const SdfBitTiles tiles{a.BX, a.BY, a.core_z};
   hipLaunchKernelGGL(k_sdfbit_seed, sdfbit_row_grid((uint32_t)a.WP, n_rows), dim3(256), 0, s, a.ev, a.r_out, a.X, a.Y, a.Z, a.WP, a.presence, tiles);
+  return hipGetLastError();
+}
+
+hipError_t launch_sdfbit_expand(const SdfBitArgs &a, const uint32_t *reached, int32_t max_iterations, hipStream_t s) {
+  const size_t n_rows = (size_t)a.Y * (size_t)a.Z;
+  const SdfBitTiles tiles{a.BX, a.BY, a.core_z};
   if ((a.X % 16) == 0 && max_iterations >= 1) {
-    hipLaunchKernelGGL(k_sdfbit_init16, sdfbit_row_grid((uint32_t)(a.X / 16), n_rows), dim3(256), 0, s, a.ev, (const uint32_t *)a.r_out, a.sdf, a.X, a.Y,
-                       a.Z, a.WP, max_iterations, tiles);
+    hipLaunchKernelGGL(k_sdfbit_expand16, sdfbit_row_grid((uint32_t)(a.X / 16), n_rows), dim3(256), 0, s, a.ev, reached, (const uint32_t *)a.planes,
+                       a.plane_words, a.sdf, a.X, a.Y, a.Z, a.WP, max_iterations, tiles);
   } else {
-    hipLaunchKernelGGL(k_sdfbit_init, dim3(((unsigned)a.X + 255u) / 256u, (unsigned)a.Y, (unsigned)a.Z), dim3(256), 0, s, a.ev, (const uint32_t *)a.r_out,
-                       a.sdf, a.X, a.Y, a.Z, a.WP, max_iterations, tiles);
+    hipLaunchKernelGGL(k_sdfbit_expand, dim3(((unsigned)a.X + 255u) / 256u, (unsigned)a.Y, (unsigned)a.Z), dim3(256), 0, s, a.ev, reached,
+                       (const uint32_t *)a.planes, a.plane_words, a.sdf, a.X, a.Y, a.Z, a.WP, max_iterations, tiles);
   }
   return hipGetLastError();
 }

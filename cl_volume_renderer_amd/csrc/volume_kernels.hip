@@ -75,6 +75,13 @@ __device__ __forceinline__ float gradient_length8(const Voxels8 &o, int h) {
 // and walks kColZ slices along z: a lane keeps the eight voxels of its (chunk, row) for the slices z - 1, z, z + 1 in registers (the z
 // taps), and slice z goes through LDS once, with a one-voxel rim, for the y and x taps.  Rim rows / voxels are loaded one slice ahead
 // like the core.  Needs rows of a multiple of 8 voxels (16-byte loads); border texel 0 (CLK_ADDRESS_CLAMP) everywhere outside.
+// A barrier that orders LDS accesses only.  __syncthreads() is also a release fence for GLOBAL memory: it waits for every outstanding
+// load of the wave (vmcnt(0)) -- which would force the next slice's prefetch below to land before slice z is even written to LDS.  The
+// loaded values are consumed through registers (the compiler waits for exactly the load it needs), nothing here communicates through
+// global memory inside a launch.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 constexpr int kColX = 256, kColY = 8, kColZ = 16, kColPitch = kColX + 16;  // LDS row: 7 unused shorts, x0 - 1, 256 voxels, x0 + 256, padding
 struct ColumnTile {
   __attribute__((aligned(16))) int16_t rows[kColY + 2][kColPitch];
@@ -110,13 +117,13 @@ __device__ __forceinline__ void walk_column_tile(const int16_t *__restrict__ vol
   slice(z_begin, cur, rim_cur, rv_cur);
   for (int z = z_begin; z < z_end; ++z) {
     slice(z + 1, nxt, rim_nxt, rv_nxt);  // in flight while slice z is processed
-    __syncthreads();                      // the previous slice's taps have been read
+    lds_barrier();                        // the previous slice's taps have been read
     *reinterpret_cast<uint4 *>(&t.rows[ry + 1][8 + cx * 8]) = cur;
     if (ry == 0) *reinterpret_cast<uint4 *>(&t.rows[0][8 + cx * 8]) = rim_cur;
     if (ry == kColY - 1) *reinterpret_cast<uint4 *>(&t.rows[kColY + 1][8 + cx * 8]) = rim_cur;
     if (cx == 0) t.rows[ry + 1][7] = (int16_t)rv_cur;
     if (cx == 31) t.rows[ry + 1][8 + kColX] = (int16_t)rv_cur;
-    __syncthreads();
+    lds_barrier();
     if (col_in) {
       int v[8], up[8], dn[8], zm[8], zp[8], gx[8], gy[8], gz[8];
       unpack8(cur, v);
