@@ -633,7 +633,10 @@ static int ensure_packed(clwh_ctx *ctx, const clwh_mem *volume, const clwh_mem *
     HIP_TRY(hipEventCreateWithFlags(&entry->ready, hipEventDisableTiming));
   }
   ctx->scene.reset();
-  entry->stale = true;  // not adoptable until described below
+  {
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    entry->stale = true;  // not adoptable until described below
+  }
   RepackArgs r;
   std::memset(&r, 0, sizeof r);
   r.volume = (const int16_t *)volume->dptr;
