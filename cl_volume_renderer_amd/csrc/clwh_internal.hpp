@@ -56,8 +56,8 @@ struct RenderArgs {
   const uint8_t *stepb;    // bricked per-step bytes (packed_volume.hpp)
   const int16_t *volume_lin;  // the caller's images (x fastest): literal taps of the rare paths
   const int8_t *sdf_lin;
-  // exit certificates (render_kernels.hip, certify_exit): eight bytes per macro cell of 16^3 voxels; byte o: a bound on the steps of a
-  // march from this cell in direction octant o until it leaves the volume, 255 = the box it crosses is not free
+  // exit certificates (render_kernels.hip, certify_exit): eight bytes per macro cell of 16^3 voxels; byte o: the smallest SDF value in
+  // the box a march from this cell in direction octant o crosses until it leaves the volume, 0 = the box is not free
   const uint8_t *macro;
   int32_t MNX, MNY, MNZ, macro_shift;  // cells per axis, log2 of the cell's edge in voxels
   int32_t cert_min_step;   // a march asks for a certificate once its next step is at least this long; 0 = certificates off

@@ -245,24 +245,19 @@ __global__ __launch_bounds__(64) void k_macro_octants(uint2 *__restrict__ macro,
     at(i) = make_uint2((v.x & ~neg.x) | (run.x & neg.x), (v.y & ~neg.y) | (run.y & neg.y));
   }
 }
-// Step 3: box minimum -> step bound.  The longest path inside the box is its diagonal (a unit direction with
-// t = e.x / |d.x| = e.y / |d.y| = e.z / |d.z| has t = |e|), every step there is max(sdf, 0.5) >= the box minimum long, so
-// diagonal / minimum steps leave the volume; + 5 covers the roundings of this bound and of the march.
-__global__ __launch_bounds__(256) void k_macro_bounds(uint2 *__restrict__ macro, int MNX, int MNY, int MNZ, int X, int Y, int Z, int shift) {
+// Step 3: the table keeps the box MINIMUM per octant (0 = the box is not free: no certificate).  Round 2 turned it into a step count
+// right here -- box diagonal / minimum + 5 -- because the diagonal is the longest path inside the box; the ray's own distance to the
+// face it leaves through is shorter and costs a dozen instructions in certify_exit: 5.79 instead of 5.16 step fetches saved per item
+// on the instrumented oracle (tools/exit_certificate.py --variants --finer, profiles/r03_exit_certificate_finer_estimate.txt).
+__global__ __launch_bounds__(256) void k_macro_bounds(uint2 *__restrict__ macro, int MNX, int MNY, int MNZ) {
   const int c = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (c >= MNX * MNY * MNZ) return;
-  const int cx = c % MNX, cy = (c / MNX) % MNY, cz = c / (MNX * MNY);
   const uint2 v = macro[c];
   uint2 r = make_uint2(0u, 0u);
   for (int o = 0; o < 8; ++o) {
-    const uint32_t m = ((o < 4 ? v.x : v.y) >> ((o & 3) * 8)) & 0xFFu;
-    const int M = 1 << shift;
-    const float ex = (o & 1) ? (float)(cx * M + M) : (float)(X - cx * M);
-    const float ey = (o & 2) ? (float)(cy * M + M) : (float)(Y - cy * M);
-    const float ez = (o & 4) ? (float)(cz * M + M) : (float)(Z - cz * M);
-    uint32_t steps = 255u;
-    if (m != 0u) steps = (uint32_t)fminf(sqrtf(ex * ex + ey * ey + ez * ez) / (float)m + 5.0f, 255.0f);
-    if (o < 4) r.x |= steps << (o * 8); else r.y |= steps << ((o - 4) * 8);
+    uint32_t m = ((o < 4 ? v.x : v.y) >> ((o & 3) * 8)) & 0xFFu;
+    if (m == 255u) m = 0u;  // (a box without any brick: never the case for a cell inside the volume)
+    if (o < 4) r.x |= m << (o * 8); else r.y |= m << ((o - 4) * 8);
   }
   macro[c] = r;
 }
@@ -468,9 +463,9 @@ constexpr int kFixupDwords = 32;  // one record = 128 B: header[4] bv_before[3] 
 // fetches, one 128-byte line each, for a position nobody needs -- are skipped and the Exit event is raised at once; the
 // result is bit-identical.  The proof is one table lookup: the ray's coordinates are monotone, so the rest of its path
 // lies in the box between its macro cell (16^3 voxels) and the volume corner its direction octant heads for, and the
-// table (k_macro_table .. k_macro_bounds) holds, per cell and octant, a bound on the steps of ANY such march if that
-// box, dilated by a brick, is free: no voxel that could be an event (a Hit needs one) and SDF values of at least
-// kCertMinStep.  The bound must fit the march's budget (a march that ran out of steps would continue as the NEXT march,
+// table (k_macro_table .. k_macro_bounds) holds, per cell and octant, the smallest SDF value of that box, dilated by a brick, if it is
+// free: no voxel that could be an event (a Hit needs one) and SDF values of at least kCertMinStep.  The ray's distance to the face it
+// leaves through, divided by that minimum, bounds the steps the march still takes; the bound must fit the march's budget (a march that ran out of steps would continue as the NEXT march,
 // with another weight, ray_marching.cl:52-73).  tools/exit_certificate.py measured the idea on the oracle first: every
 // exiting ray gets its certificate at some point, 5 of the 30 step fetches per item disappear (all far field), and not
 // one certificate in millions was wrong.
@@ -479,15 +474,21 @@ __device__ __forceinline__ bool certify_exit(const RenderArgs &a, f3 p, f3 d, in
   const unsigned cx = min((unsigned)(int)p.x >> a.macro_shift, (unsigned)a.MNX - 1u), cy = min((unsigned)(int)p.y >> a.macro_shift, (unsigned)a.MNY - 1u),
                  cz = min((unsigned)(int)p.z >> a.macro_shift, (unsigned)a.MNZ - 1u);
   const unsigned octant = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-  const int bound = a.macro[((((size_t)cz * (size_t)a.MNY + (size_t)cy) * (size_t)a.MNX + (size_t)cx) << 3) | octant];
-  // The bound counts steps of at least the box's smallest SDF value.  One kind of position is outside that reasoning: a
-  // coordinate that landed exactly ON the far face (== dimension: not exited, utility_ray.cl:112-117) reads the border SDF 0 and
-  // advances 0.5 |d| per step; with a direction component too small to move that coordinate (0.5 x 2^-10 is above half an ulp of
-  // every dimension below 2^13) the reference can crawl along the face and even run out of its 70 steps.  Such directions get
-  // no certificate and march literally; for all others the next step leaves, which the bound's + 5 covers.
+  const int box_min = a.macro[((((size_t)cz * (size_t)a.MNY + (size_t)cy) * (size_t)a.MNX + (size_t)cx) << 3) | octant];
+  // One kind of position is outside the reasoning below: a coordinate that landed exactly ON the far face (== dimension: not exited,
+  // utility_ray.cl:112-117) reads the border SDF 0 and advances 0.5 |d| per step; with a direction component too small to move that
+  // coordinate (0.5 x 2^-10 is above half an ulp of every dimension below 2^13) the reference can crawl along the face and even run
+  // out of its 70 steps.  Such directions get no certificate and march literally; for all others the next step leaves (the + 5).
   const float dmin = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
   const float dsum = d.x + d.y + d.z;  // NaN direction: the position turns NaN and never leaves
-  return bound <= budget && dmin >= 0.0009765625f && dsum == dsum;
+  // Every step inside the box is max(sdf, 0.5) >= box_min long and the direction has unit length, so the march has passed the face it
+  // leaves through -- at distance t_exit = min over the axes of (face - p) / d along the ray -- after t_exit / box_min steps; + 5 covers the
+  // roundings of this bound (v_rcp: one ulp), those of the march, and the strictness of exited_volume.  (No component of d is zero here.)
+  const float tx = (d.x < 0.0f ? p.x : (float)a.X - p.x) * __builtin_amdgcn_rcpf(fabsf(d.x));
+  const float ty = (d.y < 0.0f ? p.y : (float)a.Y - p.y) * __builtin_amdgcn_rcpf(fabsf(d.y));
+  const float tz = (d.z < 0.0f ? p.z : (float)a.Z - p.z) * __builtin_amdgcn_rcpf(fabsf(d.z));
+  const float steps = fminf(fminf(tx, ty), tz) * __builtin_amdgcn_rcpf((float)box_min) + 5.0f;
+  return box_min != 0 && steps <= (float)budget && dmin >= 0.0009765625f && dsum == dsum;
 }
 
 #ifndef CLVR_BOUNCE_WAVES_PER_SIMD
@@ -1476,7 +1477,7 @@ hipError_t launch_macro_table(const uint32_t *brick_min, int NBX, int NBY, int N
   const int lines[3] = {MNY * MNZ, MNZ * MNX, MNX * MNY};
   for (int axis = 0; axis < 3; ++axis)
     hipLaunchKernelGGL(k_macro_octants, dim3(((unsigned)lines[axis] + 63u) / 64u), dim3(64), 0, s, macro, MNX, MNY, MNZ, axis);
-  hipLaunchKernelGGL(k_macro_bounds, dim3((n + 255u) / 256u), dim3(256), 0, s, macro, MNX, MNY, MNZ, X, Y, Z, shift);
+  hipLaunchKernelGGL(k_macro_bounds, dim3((n + 255u) / 256u), dim3(256), 0, s, macro, MNX, MNY, MNZ);
   return hipGetLastError();
 }
 

@@ -333,6 +333,51 @@ static int certify_exit(const orc_render_params *p, f3 pos, f3 d, int budget) {
     }
   }
   if (!(t_exit < 1e29)) return 0;
+  if (p->cert_mode >= 5) {
+    /* pyramid variants (estimates for a table with direction bins finer than an octant): the region every march from this cell can
+     * cross when its direction's dominant axis is a and its two minor slopes |d_b / d_a|, |d_c / d_a| lie in the bin [lo, hi] of width
+     * 1 / B (B = cert_mode - 4): in the slab n cells further along a, the cells q = floor(lo max(n - 1, 0)) .. ceil(1 + hi (n + 1)) - 1
+     * along b (likewise c).  Step bound as in mode 3: the diagonal to the corner over the region's smallest SDF value. */
+    const int B = p->cert_mode - 4;
+    int a = 0;
+    if (fabs(dir[1]) > fabs(dir[a])) a = 1;
+    if (fabs(dir[2]) > fabs(dir[a])) a = 2;
+    if (dir[a] == 0.0) return 0;
+    const int b = (a + 1) % 3, cc = (a + 2) % 3;
+    const int sa = dir[a] > 0.0 ? 1 : -1, sb = dir[b] >= 0.0 ? 1 : -1, sc = dir[cc] >= 0.0 ? 1 : -1;
+    double slope_b = fabs(dir[b] / dir[a]), slope_c = fabs(dir[cc] / dir[a]);
+    int bin_b = (int)(slope_b * B), bin_c = (int)(slope_c * B);
+    if (bin_b >= B) bin_b = B - 1;
+    if (bin_c >= B) bin_c = B - 1;
+    const double lob = (double)bin_b / B, hib = (double)(bin_b + 1) / B, loc_ = (double)bin_c / B, hic = (double)(bin_c + 1) / B;
+    int region_min = 127;
+    for (int nn = 0;; ++nn) {
+      const int ia = cell[a] + sa * nn;
+      if (ia < 0 || ia >= n[a]) break;
+      const int m1 = nn > 0 ? nn - 1 : 0;
+      const int qb0 = (int)floor(lob * m1), qb1 = (int)ceil(1.0 + hib * (nn + 1)) - 1;
+      const int qc0 = (int)floor(loc_ * m1), qc1 = (int)ceil(1.0 + hic * (nn + 1)) - 1;
+      for (int qb = qb0; qb <= qb1; ++qb) {
+        const int ib = cell[b] + sb * qb;
+        if (ib < 0 || ib >= n[b]) continue;
+        for (int qc = qc0; qc <= qc1; ++qc) {
+          const int ic = cell[cc] + sc * qc;
+          if (ic < 0 || ic >= n[cc]) continue;
+          int idx[3];
+          idx[a] = ia; idx[b] = ib; idx[cc] = ic;
+          const int fm = p->macro_free_min[((int64_t)idx[2] * ny + idx[1]) * nx + idx[0]];
+          if (fm < p->cert_min_free) return 0;
+          if (fm < region_min) region_min = fm;
+        }
+      }
+    }
+    double diag2 = 0.0;
+    for (int k = 0; k < 3; ++k) {
+      const double e = dir[k] > 0.0 ? dim[k] - cell[k] * M : (dir[k] < 0.0 ? (cell[k] + 1) * M : 0.0);
+      diag2 += e * e;
+    }
+    return (int)(sqrt(diag2) / (double)region_min) + 4 <= budget;
+  }
   if (p->cert_mode != 0) {
     /* box / octant variants: no walk, a block of cells must be free with SDF values >= cert_min_free */
     int lo[3], hi[3];

@@ -22,8 +22,8 @@ def _ordered_capped_add(n_entries, entries, passes):
 
 @pytest.mark.parametrize("stride", [3, 4])
 def test_apply_contributions_equals_the_serial_rule(gpu_ctx, stride):
-    """random lists with heavy sharing (some voxels get > 256 requests within a few passes), entries outside the cache,
-    an offset > 2^31 voxels away; bit-exact against the serial restatement, whatever the kernel's parallel order"""
+    """random lists with heavy sharing (some voxels get > 256 requests within a few passes) and entries outside the cache;
+    bit-exact against the serial restatement, whatever the kernel's parallel order"""
     rng = np.random.default_rng(5 + stride)
     n_entries = 5000
     n = 40000

@@ -58,8 +58,13 @@ if variants:
     # t_exit / min_free, mode 3 bounds them by the box's diagonal / its smallest SDF value (no t_exit: ONE table lookup)
     print("scene: phantom(%d), %dx%d, default camera, default TF, 1 pass; cells of 16^3 voxels dilated by 8" % (n, w, h))
     table = macro_table(16, margin=8)
-    for mode, min_free, name in ((0, 1, "walk"), (2, 4, "octant box, t_exit / 4"), (3, 2, "octant box, diagonal / box minimum")):
-        for t in (8, 16, 32):
+    finer = "--finer" in args  # round 3: direction bins finer than an octant (dominant axis x minor-slope bins), same one-lookup form
+    modes = ((0, 1, "walk"), (2, 4, "octant box, t_exit / 4"), (3, 2, "octant box, diagonal / box minimum"))
+    if finer:
+        modes = ((3, 2, "octant box, diagonal / min (ships)"), (4, 2, "octant box, t_exit / min"), (5, 2, "dominant-axis pyramid (24 bins)"),
+                 (6, 2, "pyramid, 2 x 2 slope bins (96)"), (8, 2, "pyramid, 4 x 4 slope bins (384)"), (0, 1, "walk"))
+    for mode, min_free, name in modes:
+        for t in ((8, 16) if finer else (8, 16, 32)):
             sc = orc_ffi.Scene(vol, sdf, env, tf, (w, h), mode=orc_ffi.MODE_IMAGE_SPACE, threads=len(os.sched_getaffinity(0)))
             sc.locality = np.zeros(orc_ffi.LOCALITY_TOTAL, np.uint64)
             sc.macro_free_min, sc.macro_m, sc.cert_t, sc.cert_mode, sc.cert_min_free = table, 16, t, mode, min_free
