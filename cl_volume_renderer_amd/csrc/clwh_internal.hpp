@@ -152,7 +152,7 @@ hipError_t launch_repack(const RepackArgs &a, hipStream_t s);
 // log2 of the macro cell's edge: 16 voxels up to 512^3, then growing with the volume so that the table (8 B per cell) stays at a
 // few hundred KB, resident in every L2 -- at 2048^3 cells of 16^3 would make it 16 MiB and every look-up a miss of its own
 inline int macro_cell_shift(int X, int Y, int Z, int forced) {
-  if (forced >= 4 && forced <= 8) return forced;  // CLWH_TUNE_MACRO_SHIFT (tests)
+  if (forced >= 3 && forced <= 8) return forced;  // CLWH_TUNE_MACRO_SHIFT (tests, experiments; 3: a cell is one brick)
   int shift = 4;
   while (shift < 8 && ((int64_t)((X >> shift) + 1) * ((Y >> shift) + 1) * ((Z >> shift) + 1)) > 40000) ++shift;
   return shift;
@@ -304,7 +304,7 @@ struct clwh_ctx {
   int32_t tune_literal_gradient = 0;
   int32_t tune_unit_block_log2 = 4;
   int32_t tune_unit_group = 1, tune_unit_affinity = 0, tune_unit_queues = 8;
-  int32_t tune_cert_min_step = -1;  // CLWH_TUNE_CERT: 0 = exit certificates off; -1 = by volume size (16 at 512^3, 32 at 1024^3, 48 at 2048^3:
+  int32_t tune_cert_min_step = -1;  // CLWH_TUNE_CERT: 0 = exit certificates off; -1 = by volume size (12 at 512^3, 24 at 1024^3, 48 at 2048^3:
                                     // the best of the sweeps in profiles/r02_sweep_k_bounce_lds_state.txt)
   uint32_t tune_bounce_max_blocks = 2048;  // CLWH_TUNE_BLOCKS
   bool primary_valid = false;

@@ -57,7 +57,13 @@ if variants:
     # asks for the whole box between the cell and the volume corner of the direction's octant to be free and bounds the steps by
     # t_exit / min_free, mode 3 bounds them by the box's diagonal / its smallest SDF value (no t_exit: ONE table lookup)
     print("scene: phantom(%d), %dx%d, default camera, default TF, 1 pass; cells of 16^3 voxels dilated by 8" % (n, w, h))
-    table = macro_table(16, margin=8)
+    margin = int(args[args.index("--margin") + 1]) if "--margin" in args else 8
+    if margin != 8:
+        print("(cells dilated by %d voxels instead of a brick)" % margin)
+    cell = int(args[args.index("--cell") + 1]) if "--cell" in args else 16
+    if cell != 16:
+        print("(cells of %d^3 voxels)" % cell)
+    table = macro_table(cell, margin=margin)
     finer = "--finer" in args  # round 3: direction bins finer than an octant (dominant axis x minor-slope bins), same one-lookup form
     modes = ((0, 1, "walk"), (2, 4, "octant box, t_exit / 4"), (3, 2, "octant box, diagonal / box minimum"))
     if finer:
@@ -67,7 +73,7 @@ if variants:
         for t in ((8, 16) if finer else (8, 16, 32)):
             sc = orc_ffi.Scene(vol, sdf, env, tf, (w, h), mode=orc_ffi.MODE_IMAGE_SPACE, threads=len(os.sched_getaffinity(0)))
             sc.locality = np.zeros(orc_ffi.LOCALITY_TOTAL, np.uint64)
-            sc.macro_free_min, sc.macro_m, sc.cert_t, sc.cert_mode, sc.cert_min_free = table, 16, t, mode, min_free
+            sc.macro_free_min, sc.macro_m, sc.cert_t, sc.cert_mode, sc.cert_min_free = table, cell, t, mode, min_free
             sc.render(pos, d, scene.glibc_rand(1)[0])
             report(sc, "%-36s tried at every step >= %2d" % (name, t))
     sys.exit(0)
