@@ -1182,7 +1182,7 @@ static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settl
   // scratch: event bits (x-fastest rows), two reached-set buffers (tiled by region, padded to whole regions), the list of active
   // blocks, per-launch {count, head}, the regions' states and wake stamps
   const size_t tiled = n_blocks * (size_t)(2 * 48 * a.core_z);
-  const size_t small = n_blocks + 2 * (size_t)(n_launches + 1);
+  const size_t small = (n_blocks + 2 * (size_t)(n_launches + 1) + 1) & ~(size_t)1;  // even: the planes behind it take 8-byte atomics
   const size_t scratch_words = words + 2 * tiled + small + 7 * tiled;  // ... and the seven bit planes of the layer index
   int rc = grow(ctx, (void **)&ctx->sdf_bits, &ctx->sdf_bits_bytes, scratch_words * sizeof(uint32_t) + 2 * n_blocks);
   if (rc != CLWH_OK) return rc;

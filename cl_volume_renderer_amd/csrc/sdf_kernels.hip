@@ -795,6 +795,7 @@ __device__ __forceinline__ void sdfbit_steps(SdfBitLane &L, uint4 (*s_x)[NW][2][
         nxt[3] = L.cur[i][3] | (sdfbit_x_neighbours(u[2], u[3], 0u, clampfix[3]) & valid[3]);
         if (!y_in) nxt[0] = nxt[1] = nxt[2] = nxt[3] = 0u;  // rows beyond the volume do not exist
       }
+#ifndef CLVR_EXP_SDF_NO_REC
       if (core_strip) {
         const uint32_t nb0 = core_lane ? (nxt[1] & ~L.cur[i][1]) : 0u, nb1 = core_lane ? (nxt[2] & ~L.cur[i][2]) : 0u;
         L.rec_any[i][0] |= nb0; L.rec_any[i][1] |= nb1;
@@ -803,6 +804,7 @@ __device__ __forceinline__ void sdfbit_steps(SdfBitLane &L, uint4 (*s_x)[NW][2][
         if (k & 4) { L.rec_b2[i][0] |= nb0; L.rec_b2[i][1] |= nb1; }
         if (nb0 | nb1) L.step_mask |= 1u << k;
       }
+#endif
 #pragma unroll
       for (int j = 0; j < 4; ++j) L.cur[i][j] = nxt[j];
     }
@@ -825,7 +827,9 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
   for (uint32_t round = 0u;; ++round) {
     sdfbit_lds_barrier();  // the previous region's flags and exchange rows are no longer read
     if (tid == 0u) {
-      // dynamic: regions differ in cost (complete ones only copy); a static round-robin over the list measured 1.84 ms against 1.60
+      // dynamic: regions differ in cost (complete ones only copy); a static round-robin over the list measured 1.84 ms against 1.60.
+      // (Fetching the NEXT region's ticket and list entry while the block works on the current one -- two dependent round trips off
+      // every visit -- was measured at 1.41 ms against 1.33: two more live registers in a kernel that already spills.)
       s_entry = round == 0u ? blockIdx.x : gridDim.x + atomicAdd(a.list_head, 1u);
       s_all = 1u; s_any = 0u; s_steps = 0u; s_orx[0] = 0u; s_orx[1] = 0u;
       s_box[0] = 255; s_box[1] = -1; s_box[2] = 255; s_box[3] = -1;
@@ -952,31 +956,36 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
     // contiguous) with fire-and-forget atomic ORs -- a voxel is reached exactly once, so the launches never write the same bit -- and
     // k_sdfbit_expand turns planes + final reached set + event bits into bytes ONCE, after the last launch, with full-line stores.
     // layer index = r0 + k + 1 (1..127; r0 = 8 x launch, k the layer inside the launch as recorded bit-sliced in rec_b0..2)
+#ifndef CLVR_EXP_SDF_NO_PLANES
     if (core_strip && core_lane && y_in) {
       const uint32_t hi_lo = (uint32_t)a.r0 >> 3, hi_carry = hi_lo + 1u;  // bits 3.. of the index while k + 1 < 8 / when k + 1 == 8
       // (a plane holds at most 2^28 words: 32-bit word offsets from the plane's own, wave-uniform base keep the addresses out of the VGPRs)
       const uint32_t lane_word = (uint32_t)b * (uint32_t)kTileWords + (uint32_t)(((kBitRows * strip - kBitHalo) * kBitCoreY + ((int)lane - kBitHalo)) * 2);
 #pragma unroll
       for (int i = 0; i < kBitRows; ++i) {
+        // the row's two core words are one aligned 8-byte pair in every plane: one 64-bit OR per plane and row
+        if ((L.rec_any[i][0] | L.rec_any[i][1]) == 0u) continue;  // (then the row also lies inside the volume)
+        uint32_t v[7][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const uint32_t any = L.rec_any[i][j];
-          if (any == 0u) continue;  // (then the row also lies inside the volume)
-          const uint32_t w = lane_word + (uint32_t)(i * kBitCoreY * 2 + j);
-          const uint32_t b0 = L.rec_b0[i][j], b1 = L.rec_b1[i][j], b2 = L.rec_b2[i][j];
+          const uint32_t any = L.rec_any[i][j], b0 = L.rec_b0[i][j], b1 = L.rec_b1[i][j], b2 = L.rec_b2[i][j];
           const uint32_t m7 = b0 & b1 & b2, m = any & ~m7;  // k == 7: the index's low three bits are 0 and bit 3.. carries
-          uint32_t v[7];
-          v[0] = ~b0 & m; v[1] = (b1 ^ b0) & m; v[2] = (b2 ^ (b1 & b0)) & m;  // k + 1, bit-sliced
+          v[0][j] = ~b0 & m; v[1][j] = (b1 ^ b0) & m; v[2][j] = (b2 ^ (b1 & b0)) & m;  // k + 1, bit-sliced
 #pragma unroll
-          for (int p = 0; p < 4; ++p) v[3 + p] = (((hi_lo >> p) & 1u) ? m : 0u) | (((hi_carry >> p) & 1u) ? m7 : 0u);
-#pragma unroll
-          for (int p = 0; p < 7; ++p)
-            if (v[p]) atomicOr(a.planes + (size_t)p * a.plane_words + w, v[p]);
+          for (int p = 0; p < 4; ++p) v[3 + p][j] = (((hi_lo >> p) & 1u) ? m : 0u) | (((hi_carry >> p) & 1u) ? m7 : 0u);
         }
+        const uint32_t w = lane_word + (uint32_t)(i * kBitCoreY * 2);
+#pragma unroll
+        for (int p = 0; p < 7; ++p)
+          if (v[p][0] | v[p][1])
+            atomicOr(reinterpret_cast<unsigned long long *>(a.planes + (size_t)p * a.plane_words + w), (unsigned long long)v[p][0] | ((unsigned long long)v[p][1] << 32));
       }
     }
+#endif
 #ifdef CLVR_SDFBIT_TIMING
+#ifndef CLVR_EXP_SDF_PROBE_NOWAIT
     if (probe) __builtin_amdgcn_s_waitcnt(0);
+#endif
     const unsigned long long tq4 = wall_clock64();
 #endif
     sdfbit_lds_barrier();
