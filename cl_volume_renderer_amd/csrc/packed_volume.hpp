@@ -144,6 +144,12 @@ struct VolumePacked {
     const unsigned ux = (unsigned)(int)fx, uy = (unsigned)(int)fy, uz = (unsigned)(int)fz;
     return stepb[part_x<SMALL>(ux) + part_y<SMALL>(uy) + part_z<SMALL>(uz)];
   }
+  // the same fetch as an agent-scope load (`sc1`): served by L2, leaves no line in the CU's L1
+  template <int SMALL>
+  __device__ __forceinline__ unsigned step_marched_past_l1(float fx, float fy, float fz) const {
+    const unsigned ux = (unsigned)(int)fx, uy = (unsigned)(int)fy, uz = (unsigned)(int)fz;
+    return __hip_atomic_load(stepb + (part_x<SMALL>(ux) + part_y<SMALL>(uy) + part_z<SMALL>(uz)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 };
 template <> struct VolumePacked::Index<1> { using type = uint32_t; };
 template <> struct VolumePacked::Index<2> { using type = uint32_t; };

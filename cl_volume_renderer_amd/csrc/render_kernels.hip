@@ -694,7 +694,32 @@ __global__ __launch_bounds__(kBounceThreads, CLVR_BOUNCE_WAVES_PER_SIMD) void k_
                                    __float_as_uint(ray.origin.z) < __float_as_uint((float)a.Z);
             if (has_voxel) {
               // the step byte says everything a table without `gradient` rules needs (classify_step's last case)
+#ifdef CLVR_EXP_FAR_SC1  // experiment: the fetch after a long step (a new line, rarely used again) does not allocate in L1
+              const unsigned q = sd >= CLVR_EXP_FAR_SC1 ? vol.template step_marched_past_l1<SMALL>(ray.origin.x, ray.origin.y, ray.origin.z)
+                                                        : vol.template step_marched<SMALL>(ray.origin.x, ray.origin.y, ray.origin.z);
+#else
               const unsigned q = vol.template step_marched<SMALL>(ray.origin.x, ray.origin.y, ray.origin.z);
+#endif
+#ifdef CLVR_EXP_STEP_LOADPAD  // experiment: N more loads per step, of neighbours inside the line just requested (address unit / L1 sensitivity)
+              {
+                unsigned pad_acc = 0u;
+#pragma unroll
+                for (int k = 1; k <= CLVR_EXP_STEP_LOADPAD; ++k)
+                  pad_acc += vol.template step_marched<SMALL>((float)(f2i(ray.origin.x) ^ k), ray.origin.y, ray.origin.z);
+                if (pad_acc == 255u * CLVR_EXP_STEP_LOADPAD) atten = 1.0f;  // (possible in principle: a timing experiment, not a product build)
+              }
+#endif
+#ifdef CLVR_EXP_STEP_L2PAD  // experiment: N more loads per step from random lines of the first MiB of the step bytes (L2 hits, L1 misses)
+              {
+                unsigned pad_acc = 0u, hsh = __float_as_uint(ray.origin.x) * 2654435761u + __float_as_uint(ray.origin.y) * 40503u + __float_as_uint(ray.origin.z);
+#pragma unroll
+                for (int k = 0; k < CLVR_EXP_STEP_L2PAD; ++k) {
+                  hsh ^= hsh << 13; hsh ^= hsh >> 17; hsh ^= hsh << 5;
+                  pad_acc += vol.stepb[hsh & 0xFFFFFu];
+                }
+                if (pad_acc == 255u * CLVR_EXP_STEP_L2PAD) atten = 1.0f;
+              }
+#endif
               sd = (int)(q & 0x7Fu);
               if (q & 0x80u) st = ST_EVENT + EV_HIT_COLOR_PENDING;
               else if (steps_left == 0) st = ST_EVENT + EV_NONE;
