@@ -714,8 +714,10 @@ def main():
                               "what": "bytes ACTUALLY moved at the L2's memory side per launch (profiled run) / this run's launch "
                                       "duration: every missing 1-byte gather moves a 128-byte line"} if tb else None),
             "traffic_note": (tb or {}).get("note", "GB per launch from rocprofv3 --pmc (profiles/r02_traffic.json); null: this launch shape was not profiled"),
-            "limiter": "dependent 1-byte gathers: the rate of L2-missing 128-byte lines (about 41 G/s of the 48-54 G/s a plain random-load "
-                       "probe reaches) together with VALU issue (84 % busy), not algorithmic HBM bytes (DESIGN.md 4)",
+            "limiter": "dependent 1-byte gathers, not algorithmic HBM bytes: every gather that misses L1 moves a 128-byte line over the CU's "
+                       "fill path (3.3 ns per thousand, measured), every L2 miss a line from the fabric (50-54 G lines/s, a plain random-load "
+                       "probe's rate); on the 512^3 default-TF job those two and VALU issue (85 % busy) are of comparable size, larger jobs run "
+                       "at the line rate of their misses (DESIGN.md 4, profiles/r03_k_bounce_memory_pipe_sensitivity.txt)",
             "bytes_per_sample": round(bytes_bounce(c, grad) / float(own_px), 3),
             "survey_formula_with_per_step_gradient_taps": ({
                 "what": "SURVEY 8d's formula as written credits a TF that reads `gradient` with 7 volume texels per classified step; "
