@@ -92,6 +92,31 @@ def test_apply_clip(gpu_ctx):
     k.release()
 
 
+@pytest.mark.parametrize("start,length,global_size", [
+    ((5, 7, 3), (24, 20, 16), None),      # eight voxels per lane, source runs at odd voxels
+    ((30, 25, 20), (24, 20, 20), None),   # runs that cross the image's far faces: border 0 (x voxel by voxel, rows and slices whole)
+    ((0, 0, 0), (48, 40, 36), None),      # the whole volume
+    ((3, 1, 2), (20, 12, 8), None),       # rows that are no multiple of eight: the one-voxel kernel
+    ((4, 4, 4), (20, 12, 8), (24, 16, 8)),  # a clip length shorter than the destination image: the voxels beyond it keep their value
+])
+def test_apply_clip_shapes(gpu_ctx, start, length, global_size):
+    vol = scene.phantom(48, dims=(48, 40, 36))
+    v = gpu_ctx.image_from(vol)
+    dims = global_size or length
+    before = np.full((dims[2], dims[1], dims[0]), 77, np.int16)
+    dst = gpu_ctx.image_from(before)
+    b_start = gpu_ctx.buffer_from(np.array(start, np.uint32))
+    b_len = gpu_ctx.buffer_from(np.array(list(length) + [4], np.uint32))
+    k = gpu_ctx.kernel("reference_volume_clip.cl", "apply_clip")
+    k.launch(list(dims), [4, 4, 4], v, dst, b_start, b_len)
+    want = before.copy()
+    want[: length[2], : length[1], : length[0]] = orc_volume.apply_clip(vol, start, length)
+    assert np.array_equal(dst.pull(), want)
+    for m in (v, dst, b_start, b_len):
+        m.release()
+    k.release()
+
+
 @pytest.mark.parametrize("dims", [(192, 160, 144), (200, 170, 150), (2056, 6, 5)])
 def test_stats_and_histogram_at_scale(gpu_ctx, dims):
     """fetch_stats and tf_sort_values are persistent grids (a lane takes eight voxels, 16-byte loads when the row length allows; the
