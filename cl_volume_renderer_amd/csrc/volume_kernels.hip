@@ -404,7 +404,11 @@ __global__ __launch_bounds__(kBfB * kBfB * kBfB / 2) void k_bilateral_filter2(co
 // across a wave and sent one global atomic per wave and distinct bin: still 94 ms at 512^3 on the few hot bins.)  Bins outside the width x height
 // frame (value == max_value rounds to column `width`; values below min_value go negative -- both write
 // out of bounds in the reference) are dropped.
-constexpr int kHistSlotsLog2 = 13, kHistSlots = 1 << kHistSlotsLog2;
+// 4096 slots (32 KB): four blocks per CU.  8192 slots left two (0.68 ms at 512^3 against 0.54); 2048: 0.55 ms; 1024: 0.81 ms (bins that find
+// no slot go to memory).  Also measured, without gain (profiles/r03_volume_kernels_512.txt): the first probes of a lane's eight updates in
+// flight together; both bin coordinates from exact tables instead of sqrt / divide / round (VALU 69 % -> 35 % busy, same time: the walk's
+// slice takes 9 us here against 2.3 us in k_fetch_stats_columns, and it is not issue, LDS cycles or same-bin atomics that it waits for).
+constexpr int kHistSlotsLog2 = 12, kHistSlots = 1 << kHistSlotsLog2;
 __global__ __launch_bounds__(256) void k_tf_sort_values(const int16_t *__restrict__ vol, int X, int Y, int Z, uint32_t *frame,
                                                         int width, int height, float min_value, float max_value,
                                                         float min_gradient, float max_gradient) {
