@@ -1577,10 +1577,13 @@ hipError_t launch_bounce(const RenderArgs &a_in, hipStream_t s) {
 // finish the samples whose environment lookups the fast path could not certify
 hipError_t launch_env_fixup(const RenderArgs &a, hipStream_t s) {
   if ((uint64_t)a.n_hits * (uint64_t)a.n_seeds == 0) return hipSuccess;  // n_hits is the pixel count when the real one is on the device
+  // (the record count is on the device: a grid-stride loop; a 64-seed launch leaves tens of thousands of records of binary64 work:
+  // 47.6 us on 64 blocks, 19.6 on 256, 20.2 on 1024)
+  const unsigned blocks = a.n_seeds > 1 ? 256u : 64u;
   if (a.mode == CLWH_ACCUM_VOXEL_CACHE)
-    hipLaunchKernelGGL(k_env_fixup<CLWH_ACCUM_VOXEL_CACHE>, dim3(64), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_env_fixup<CLWH_ACCUM_VOXEL_CACHE>, dim3(blocks), dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL(k_env_fixup<CLWH_ACCUM_IMAGE_SPACE>, dim3(64), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_env_fixup<CLWH_ACCUM_IMAGE_SPACE>, dim3(blocks), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
