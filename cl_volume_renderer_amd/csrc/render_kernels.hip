@@ -67,13 +67,17 @@ __device__ __forceinline__ unsigned lane_id() { return prefix_count(~0ull); }
 
 // ------------------------------------------------------------------------------------------------
 // volume + SDF + transfer function -> bricked step bytes + hit records (packed_volume.hpp).
-// A block turns a 32 x 8 x 8 box of the caller's x-fastest images (four bricks side by side) into brick order: the box
+// A block turns a 64 x 8 x 8 box of the caller's x-fastest images (eight bricks side by side: whole 128-byte lines of the volume; with
+// 32 voxels two blocks -- on two XCDs -- each fetched every line: 1.7 GB read for 0.4 GB of images at 512^3) into brick order: the box
 // and its one-voxel halo are read ONCE with coalesced loads (a wave reads 64 consecutive voxels of a row) and staged
 // in LDS; the central differences and the class come from there; every wave then writes whole 4x4x4 sub-bricks (512
 // contiguous bytes of hit records, 64 of step bytes).  The first version let each wave gather its sub-brick's rows and
 // the six taps straight from global memory: 8-byte pieces of 128-byte lines, 2.1 GB fetched for a 0.27 GB volume.
-constexpr int kRepackX = 32;        // voxels per block along x
-constexpr int kRepackPitch = 48;    // LDS row: 7 unused shorts, x0 - 1, the 32 voxels from a 16-byte aligned offset, x0 + 32, padding
+#ifndef CLVR_REPACK_X
+#define CLVR_REPACK_X 64
+#endif
+constexpr int kRepackX = CLVR_REPACK_X;  // voxels per block along x (32 or 64)
+constexpr int kRepackPitch = kRepackX + 16;  // LDS row: 7 unused shorts, x0 - 1, the box's voxels from a 16-byte aligned offset, one voxel beyond, padding
 constexpr int kRepackX0 = 8;        // index of voxel x0 in a row
 __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
   __shared__ __attribute__((aligned(16))) int16_t s_val[10][10][kRepackPitch];  // [z][y][kRepackX0 + lx], lx = -1 .. 32: values with halo
@@ -83,8 +87,9 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
   if ((a.X & 15) == 0 && x0 + kRepackX <= a.X && ((reinterpret_cast<uintptr_t>(a.volume) | reinterpret_cast<uintptr_t>(a.sdf)) & 15u) == 0u) {
     // rows of a multiple of 16 voxels, box inside the volume along x: a lane moves 16 bytes (the staging loop below spent more
     // instructions on its per-voxel index arithmetic than the classification that follows)
-    for (unsigned i = tid; i < 10u * 10u * 4u; i += 256u) {
-      const unsigned row = i >> 2, c = i & 3u;
+    constexpr unsigned kChunks = kRepackX / 8;  // 16-byte pieces of a row of values
+    for (unsigned i = tid; i < 10u * 10u * kChunks; i += 256u) {
+      const unsigned row = i / kChunks, c = i % kChunks;
       const int ry = (int)(row % 10u), rz = (int)(row / 10u);
       const int y = y0 - 1 + ry, z = z0 - 1 + rz;
       uint4 v = uint4{0u, 0u, 0u, 0u};  // border texel (utility_filter.cl:2-35 reads with CLK_ADDRESS_CLAMP: 0 outside)
@@ -93,14 +98,15 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
         const int16_t *src = a.volume + ((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x0;
         v = *reinterpret_cast<const uint4 *>(src + 8 * c);
         if (c == 0u && x0 > 0) left = src[-1];
-        if (c == 3u && x0 + kRepackX < a.X) right = src[kRepackX];
+        if (c == kChunks - 1u && x0 + kRepackX < a.X) right = src[kRepackX];
       }
       *reinterpret_cast<uint4 *>(&s_val[rz][ry][kRepackX0 + 8 * (int)c]) = v;
       if (c == 0u) s_val[rz][ry][kRepackX0 - 1] = left;
-      if (c == 3u) s_val[rz][ry][kRepackX0 + kRepackX] = right;
+      if (c == kChunks - 1u) s_val[rz][ry][kRepackX0 + kRepackX] = right;
     }
-    if (tid < 8u * 8u * 2u) {
-      const unsigned row = tid >> 1, c = tid & 1u;
+    constexpr unsigned kSdfChunks = kRepackX / 16;  // 16-byte pieces of a row of SDF bytes
+    for (unsigned i = tid; i < 8u * 8u * kSdfChunks; i += 256u) {
+      const unsigned row = i / kSdfChunks, c = i % kSdfChunks;
       const int ry = (int)(row & 7u), rz = (int)(row >> 3);
       const int y = y0 + ry, z = z0 + rz;
       uint4 v = uint4{0u, 0u, 0u, 0u};
@@ -128,9 +134,9 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
   __syncthreads();
   const unsigned wave = tid >> 6, lane = tid & 63u;
   const size_t brick_row = ((size_t)blockIdx.z * (size_t)a.NBY + (size_t)blockIdx.y) * (size_t)a.NBX;
-  for (unsigned sb = wave; sb < 32u; sb += 4u) {  // 4 bricks x 8 sub-bricks
+  for (unsigned sb = wave; sb < (unsigned)kRepackX; sb += 4u) {  // kRepackX / 8 bricks x 8 sub-bricks
     const unsigned bq = sb >> 3, sub = sb & 7u;
-    const int bx = (int)blockIdx.x * 4 + (int)bq;
+    const int bx = (int)blockIdx.x * (kRepackX / 8) + (int)bq;
     if (bx >= a.NBX) continue;
     unsigned ix, iy, iz;
     VolumePacked::inner_coords(sub * 64u + lane, ix, iy, iz);
@@ -1494,7 +1500,7 @@ __global__ __launch_bounds__(64) void k_frame_from_tiles(const RenderArgs a, con
 
 // ------------------------------------------------------------------------------------------------
 hipError_t launch_repack(const RepackArgs &a, hipStream_t s) {
-  const dim3 grid(((unsigned)a.NBX + 3u) / 4u, (unsigned)a.NBY, (unsigned)a.NBZ);  // every dimension far below the 2^32 work-item limit
+  const dim3 grid(((unsigned)a.NBX + (unsigned)(kRepackX / 8) - 1u) / (unsigned)(kRepackX / 8), (unsigned)a.NBY, (unsigned)a.NBZ);  // every dimension far below the 2^32 work-item limit
   hipLaunchKernelGGL(k_repack, grid, dim3(256), 0, s, a);
   return hipGetLastError();
 }
