@@ -218,7 +218,7 @@ hipError_t launch_sdfbit_events(const SdfArgs &a, uint32_t *ev, int32_t WP, hipS
 hipError_t launch_sdfbit_seed(const SdfBitArgs &a, hipStream_t s);                                // seeds into a.r_out
 hipError_t launch_sdfbit_expand(const SdfBitArgs &a, const uint32_t *reached, int32_t max_iterations, hipStream_t s);  // bit planes + final reached set -> a.sdf
 hipError_t launch_sdfbit_state(const SdfBitArgs &a, hipStream_t s);                              // block states of a.r_in
-hipError_t launch_sdfbit_layers(const SdfBitArgs &a, int waves, unsigned grid_blocks, hipStream_t s);
+hipError_t launch_sdfbit_layers(const SdfBitArgs &a, int waves, unsigned grid_blocks, bool rec_in_lds, hipStream_t s);
 
 hipError_t launch_sdf_base(const SdfArgs &a, hipStream_t s);
 hipError_t launch_sdf_base_front(const SdfArgs &a, uint8_t *flags, int32_t TX, int32_t TY, hipStream_t s);
@@ -335,6 +335,7 @@ struct clwh_ctx {
   size_t sdf_bits_bytes = 0;
   int32_t tune_sdfbit_waves = 8;    // CLWH_TUNE_SDFBIT_WAVES: 8 or 16 waves per block of the bit-parallel build
   int32_t tune_sdfbit_grid = 512;   // CLWH_TUNE_SDFBIT_GRID: its persistent grid
+  int32_t tune_sdfbit_rec_lds = 0;  // CLWH_TUNE_SDFBIT_REC=lds: the layer records in LDS, three blocks of eight waves per CU (grid x 3 / 2)
   int32_t tune_sdf_front = 0;       // CLWH_TUNE_SDF=front: the byte-front build (one launch per layer) instead of the bit-parallel one
   // derived packed volume: hit records (8 B per voxel of the brick grid), the step bytes (1 B), the per-brick minima (4 B per
   // brick), the macro-cell table -- shared with every other context of the device that renders the same scene

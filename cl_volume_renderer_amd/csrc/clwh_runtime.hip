@@ -211,6 +211,7 @@ int clwh_ctx_create_on_stream(int device, void *hip_stream, clwh_ctx **out) {
   if (const char *e = std::getenv("CLWH_TUNE_SDF")) c->tune_sdf_front = std::strcmp(e, "front") == 0;
   if (const char *e = std::getenv("CLWH_TUNE_SDFBIT_WAVES")) c->tune_sdfbit_waves = std::atoi(e) == 16 ? 16 : 8;
   if (const char *e = std::getenv("CLWH_TUNE_SDFBIT_GRID")) c->tune_sdfbit_grid = std::max(1, std::atoi(e));
+  if (const char *e = std::getenv("CLWH_TUNE_SDFBIT_REC")) c->tune_sdfbit_rec_lds = std::strcmp(e, "lds") == 0 ? 1 : 0;
   if (const char *e = std::getenv("CLWH_TUNE_CERT")) c->tune_cert_min_step = std::max(0, std::min(127, std::atoi(e)));
   *out = c;
   return CLWH_OK;
@@ -1220,7 +1221,8 @@ static int sdf_build_bits(clwh_ctx *ctx, SdfArgs &b, std::vector<int32_t> &settl
     a.r_out = reached[(t + 1) & 1];
     a.list_count = queue + 2 * t;
     a.list_head = queue + 2 * t + 1;
-    HIP_TRY(launch_sdfbit_layers(a, waves, (unsigned)ctx->tune_sdfbit_grid * (waves == 16 ? 1u : 2u) / 2u, ctx->stream));
+    const bool rec_lds = waves == 8 && ctx->tune_sdfbit_rec_lds != 0;
+    HIP_TRY(launch_sdfbit_layers(a, waves, (unsigned)ctx->tune_sdfbit_grid * (waves == 16 ? 1u : (rec_lds ? 3u : 2u)) / 2u, rec_lds, ctx->stream));
   }
   // the values, once: the reached set after the last launch is the one it wrote (regions complete earlier are complete in both)
   HIP_TRY(launch_sdfbit_expand(a, reached[t & 1], b.max_iterations, ctx->stream));

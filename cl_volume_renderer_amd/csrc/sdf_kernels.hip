@@ -742,10 +742,18 @@ struct SdfBitLane {
   uint32_t step_mask;
 };
 
-template <int NW, bool INTERIOR>
-__device__ __forceinline__ void sdfbit_steps(SdfBitLane &L, uint4 (*s_x)[NW][2][64], int steps, int strip, unsigned lane, bool core_lane, bool core_strip,
+// REC_LDS: the bit-sliced layer records (32 registers of a lane) live in LDS instead -- `rec` points at this lane's first word, the words of
+// (plane, row, word) lie kRecStride apart -- and the exchange rows are single-buffered (a second barrier per layer): 41 KB of LDS and 80
+// VGPRs, three blocks per CU instead of two.
+template <int NW>
+struct SdfBitRec {
+  static constexpr int kCoreStrips = NW - 2 * kBitHalo / kBitRows, kStride = kCoreStrips * kBitCoreY;  // words between consecutive (plane, row, word)
+};
+template <int NW, bool INTERIOR, bool REC_LDS>
+__device__ __forceinline__ void sdfbit_steps(SdfBitLane &L, uint4 (*s_x)[NW][2][64], uint32_t *rec, int steps, int strip, unsigned lane, bool core_lane, bool core_strip,
                                              const uint32_t (&valid)[4], const uint32_t (&clampfix)[4], bool y_in, bool y_border, int zfirst, int Z) {
   constexpr int kRegZ = kBitRows * NW;
+  constexpr int kRecStride = SdfBitRec<NW>::kStride;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     if (k >= steps) break;
@@ -760,13 +768,14 @@ __device__ __forceinline__ void sdfbit_steps(SdfBitLane &L, uint4 (*s_x)[NW][2][
         v[i][j] = sdfbit_lane_prev(L.cur[i][j]) | sdfbit_lane_next(L.cur[i][j]);
         if (!INTERIOR) v[i][j] |= y_border ? L.cur[i][j] : 0u;
       }
-    uint4 *xbuf = &s_x[k & 1][0][0][0];
+    uint4 *xbuf = &s_x[REC_LDS ? 0 : (k & 1)][0][0][0];
     xbuf[(strip * 2 + 0) * 64 + lane] = uint4{v[0][0], v[0][1], v[0][2], v[0][3]};
     xbuf[(strip * 2 + 1) * 64 + lane] = uint4{v[kBitRows - 1][0], v[kBitRows - 1][1], v[kBitRows - 1][2], v[kBitRows - 1][3]};
     sdfbit_lds_barrier();
     uint4 below = uint4{0u, 0u, 0u, 0u}, above = uint4{0u, 0u, 0u, 0u};
     if (strip > 0) below = xbuf[((strip - 1) * 2 + 1) * 64 + lane];
     if (strip < NW - 1) above = xbuf[((strip + 1) * 2 + 0) * 64 + lane];
+    if (REC_LDS) sdfbit_lds_barrier();  // one buffer: everybody has read its neighbours' rows before the next layer overwrites them
 #pragma unroll
     for (int i = 0; i < kBitRows; ++i) {
       const int rz = kBitRows * strip + i, gz = zfirst + i;
@@ -798,10 +807,22 @@ __device__ __forceinline__ void sdfbit_steps(SdfBitLane &L, uint4 (*s_x)[NW][2][
 #ifndef CLVR_EXP_SDF_NO_REC
       if (core_strip) {
         const uint32_t nb0 = core_lane ? (nxt[1] & ~L.cur[i][1]) : 0u, nb1 = core_lane ? (nxt[2] & ~L.cur[i][2]) : 0u;
-        L.rec_any[i][0] |= nb0; L.rec_any[i][1] |= nb1;
-        if (k & 1) { L.rec_b0[i][0] |= nb0; L.rec_b0[i][1] |= nb1; }
-        if (k & 2) { L.rec_b1[i][0] |= nb0; L.rec_b1[i][1] |= nb1; }
-        if (k & 4) { L.rec_b2[i][0] |= nb0; L.rec_b2[i][1] |= nb1; }
+        if (REC_LDS) {
+          // ds_or without return; plane p of (row i, word j) at rec[((p * kBitRows + i) * 2 + j) * kRecStride]; plane 0 = "reached in this launch"
+          if (nb0) { atomicOr(rec + ((0 * kBitRows + i) * 2 + 0) * kRecStride, nb0);
+                     if (k & 1) atomicOr(rec + ((1 * kBitRows + i) * 2 + 0) * kRecStride, nb0);
+                     if (k & 2) atomicOr(rec + ((2 * kBitRows + i) * 2 + 0) * kRecStride, nb0);
+                     if (k & 4) atomicOr(rec + ((3 * kBitRows + i) * 2 + 0) * kRecStride, nb0); }
+          if (nb1) { atomicOr(rec + ((0 * kBitRows + i) * 2 + 1) * kRecStride, nb1);
+                     if (k & 1) atomicOr(rec + ((1 * kBitRows + i) * 2 + 1) * kRecStride, nb1);
+                     if (k & 2) atomicOr(rec + ((2 * kBitRows + i) * 2 + 1) * kRecStride, nb1);
+                     if (k & 4) atomicOr(rec + ((3 * kBitRows + i) * 2 + 1) * kRecStride, nb1); }
+        } else {
+          L.rec_any[i][0] |= nb0; L.rec_any[i][1] |= nb1;
+          if (k & 1) { L.rec_b0[i][0] |= nb0; L.rec_b0[i][1] |= nb1; }
+          if (k & 2) { L.rec_b1[i][0] |= nb0; L.rec_b1[i][1] |= nb1; }
+          if (k & 4) { L.rec_b2[i][0] |= nb0; L.rec_b2[i][1] |= nb1; }
+        }
         if (nb0 | nb1) L.step_mask |= 1u << k;
       }
 #endif
@@ -813,10 +834,14 @@ __device__ __forceinline__ void sdfbit_steps(SdfBitLane &L, uint4 (*s_x)[NW][2][
 
 // The grid is persistent: its blocks take the active regions from the list k_sdfbit_list made (a launch over ALL regions
 // spent 30 us on the inactive ones alone); a block's first region is list[blockIdx.x], the following ones come from a queue.
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a) {
+template <int NW, bool REC_LDS>
+__global__ __launch_bounds__(64 * NW, REC_LDS ? 6 : 4) void k_sdfbit_layers(const SdfBitArgs a) {
   constexpr int kRegZ = kBitRows * NW, kCoreZ = kRegZ - 2 * kBitHalo;
-  __shared__ uint4 s_x[2][NW][2][64];
+  __shared__ uint4 s_x[REC_LDS ? 1 : 2][NW][2][64];
+  constexpr int kRecStride = SdfBitRec<NW>::kStride;
+  __shared__ uint32_t s_rec[REC_LDS ? 4 * kBitRows * 2 * kRecStride : 1];
+  if (REC_LDS)
+    for (int i = (int)threadIdx.x; i < 4 * kBitRows * 2 * kRecStride; i += 64 * NW) s_rec[i] = 0u;  // (a region leaves them cleared)
   __shared__ uint32_t s_all, s_any, s_steps, s_entry, s_orx[2];
   __shared__ int s_box[4];  // min y, max y, min z, max z of the core's reached voxels
   const unsigned tid = threadIdx.x, lane = tid & 63u;
@@ -905,17 +930,20 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
       L.cur[i][2] = row_in ? w12.y : 0u;
       L.cur[i][3] = right_in ? w3 : 0u;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) L.rec_any[i][j] = L.rec_b0[i][j] = L.rec_b1[i][j] = L.rec_b2[i][j] = 0u;
+      for (int j = 0; j < 2; ++j)
+        if (!REC_LDS) L.rec_any[i][j] = L.rec_b0[i][j] = L.rec_b1[i][j] = L.rec_b2[i][j] = 0u;
     }
     L.step_mask = 0u;
 #ifdef CLVR_SDFBIT_TIMING
     if (probe) __builtin_amdgcn_s_waitcnt(0);
     const unsigned long long tq2 = wall_clock64();
 #endif
+    // this lane's first record word (core lanes of core strips only; the others never touch the records)
+    uint32_t *rec = s_rec + (core_strip && core_lane ? (strip - kBitHalo / kBitRows) * kBitCoreY + ((int)lane - kBitHalo) : 0);
     if (interior)
-      sdfbit_steps<NW, true>(L, s_x, a.steps, strip, lane, core_lane, core_strip, valid, clampfix, y_in, y_border, zfirst, a.Z);
+      sdfbit_steps<NW, true, REC_LDS>(L, s_x, rec, a.steps, strip, lane, core_lane, core_strip, valid, clampfix, y_in, y_border, zfirst, a.Z);
     else
-      sdfbit_steps<NW, false>(L, s_x, a.steps, strip, lane, core_lane, core_strip, valid, clampfix, y_in, y_border, zfirst, a.Z);
+      sdfbit_steps<NW, false, REC_LDS>(L, s_x, rec, a.steps, strip, lane, core_lane, core_strip, valid, clampfix, y_in, y_border, zfirst, a.Z);
 
 #ifdef CLVR_SDFBIT_TIMING
     const unsigned long long tq3 = wall_clock64();
@@ -964,11 +992,31 @@ __global__ __launch_bounds__(64 * NW, 4) void k_sdfbit_layers(const SdfBitArgs a
 #pragma unroll
       for (int i = 0; i < kBitRows; ++i) {
         // the row's two core words are one aligned 8-byte pair in every plane: one 64-bit OR per plane and row
-        if ((L.rec_any[i][0] | L.rec_any[i][1]) == 0u) continue;  // (then the row also lies inside the volume)
+        uint32_t r_any[2], r_b0[2], r_b1[2], r_b2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (REC_LDS) {
+            r_any[j] = rec[((0 * kBitRows + i) * 2 + j) * kRecStride];
+            r_b0[j] = r_b1[j] = r_b2[j] = 0u;
+          } else {
+            r_any[j] = L.rec_any[i][j]; r_b0[j] = L.rec_b0[i][j]; r_b1[j] = L.rec_b1[i][j]; r_b2[j] = L.rec_b2[i][j];
+          }
+        }
+        if ((r_any[0] | r_any[1]) == 0u) continue;  // (then the row also lies inside the volume)
+        if (REC_LDS) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            r_b0[j] = rec[((1 * kBitRows + i) * 2 + j) * kRecStride];
+            r_b1[j] = rec[((2 * kBitRows + i) * 2 + j) * kRecStride];
+            r_b2[j] = rec[((3 * kBitRows + i) * 2 + j) * kRecStride];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) rec[((p * kBitRows + i) * 2 + j) * kRecStride] = 0u;  // cleared for the block's next region
+          }
+        }
         uint32_t v[7][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const uint32_t any = L.rec_any[i][j], b0 = L.rec_b0[i][j], b1 = L.rec_b1[i][j], b2 = L.rec_b2[i][j];
+          const uint32_t any = r_any[j], b0 = r_b0[j], b1 = r_b1[j], b2 = r_b2[j];
           const uint32_t m7 = b0 & b1 & b2, m = any & ~m7;  // k == 7: the index's low three bits are 0 and bit 3.. carries
           v[0][j] = ~b0 & m; v[1][j] = (b1 ^ b0) & m; v[2][j] = (b2 ^ (b1 & b0)) & m;  // k + 1, bit-sliced
 #pragma unroll
@@ -1057,14 +1105,16 @@ hipError_t launch_sdfbit_state(const SdfBitArgs &a, hipStream_t s) {
 }
 
 // one launch = the list of the regions that can change + up to eight layers on them (persistent grid of `grid_blocks`)
-hipError_t launch_sdfbit_layers(const SdfBitArgs &a, int waves, unsigned grid_blocks, hipStream_t s) {
+hipError_t launch_sdfbit_layers(const SdfBitArgs &a, int waves, unsigned grid_blocks, bool rec_in_lds, hipStream_t s) {
   const unsigned n_blocks = (unsigned)(a.BX * a.BY * a.BZ);
   hipLaunchKernelGGL(k_sdfbit_list, dim3(std::min((n_blocks + 255u) / 256u, 1024u)), dim3(256), 0, s, a);
   const unsigned grid = std::min(n_blocks, grid_blocks);
   if (waves == 16)
-    hipLaunchKernelGGL(k_sdfbit_layers<16>, dim3(grid), dim3(64 * 16), 0, s, a);
+    hipLaunchKernelGGL((k_sdfbit_layers<16, false>), dim3(grid), dim3(64 * 16), 0, s, a);
+  else if (rec_in_lds)
+    hipLaunchKernelGGL((k_sdfbit_layers<8, true>), dim3(grid), dim3(64 * 8), 0, s, a);
   else
-    hipLaunchKernelGGL(k_sdfbit_layers<8>, dim3(grid), dim3(64 * 8), 0, s, a);
+    hipLaunchKernelGGL((k_sdfbit_layers<8, false>), dim3(grid), dim3(64 * 8), 0, s, a);
   return hipGetLastError();
 }
 

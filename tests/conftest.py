@@ -148,6 +148,15 @@ def gpu_ctx_sdf_waves16():
 
 
 @pytest.fixture(scope="session")
+def gpu_ctx_sdf_rec_lds():
+    """the bit-parallel SDF build with the layer records in LDS (80 VGPRs, three blocks per CU; CLWH_TUNE_SDFBIT_REC=lds: the round-3
+    occupancy experiment, csrc/sdf_kernels.hip)"""
+    ctx = _ctx_with_env({"CLWH_TUNE_SDFBIT_REC": "lds"})
+    yield ctx
+    ctx.destroy()
+
+
+@pytest.fixture(scope="session")
 def gpu_ctx_half_grid():
     """k_bounce on half the persistent grid (CLWH_TUNE_BLOCKS=1024): what bench.py asks for when two frame jobs of a multi-rank run
     are in flight"""

@@ -139,13 +139,14 @@ def _blobs(dims, seed):
     return np.ascontiguousarray(np.clip(vol, -1000, 1100).astype(np.int16))
 
 
-@pytest.mark.parametrize("variant", ["bits", "bits16", "front"])
+@pytest.mark.parametrize("variant", ["bits", "bits16", "bits_rec_lds", "front"])
 @pytest.mark.parametrize("dims", [(200, 170, 150), (65, 49, 17), (2, 40, 40), (130, 3, 7), (31, 97, 129)])
-def test_every_build_variant_on_awkward_shapes(gpu_ctx, gpu_ctx_sdf_waves16, gpu_ctx_sdf_front, orc, variant, dims):
+def test_every_build_variant_on_awkward_shapes(gpu_ctx, gpu_ctx_sdf_waves16, gpu_ctx_sdf_rec_lds, gpu_ctx_sdf_front, orc, variant, dims):
     """The bit-parallel build works on regions of 64 x 48 x 16 (or 48) voxels with 8-voxel halos, rows of 32-bit words and a
     clamped neighbourhood at the faces: sizes that are no multiple of any of these, one-voxel-thick volumes, and surfaces that
-    run into the faces -- every value and the reference's launch count against the oracle, for all three build paths."""
-    ctx = {"bits": gpu_ctx, "bits16": gpu_ctx_sdf_waves16, "front": gpu_ctx_sdf_front}[variant]
+    run into the faces -- every value and the reference's launch count against the oracle, for all build paths (the 8-wave
+    blocks also with their layer records in LDS)."""
+    ctx = {"bits": gpu_ctx, "bits16": gpu_ctx_sdf_waves16, "bits_rec_lds": gpu_ctx_sdf_rec_lds, "front": gpu_ctx_sdf_front}[variant]
     vol = _blobs(dims, seed=sum(dims))
     tf = scene.tf_default_source()
     want, n_want, _ = orc.sdf_build(vol, orc.parse_tf(tf))
