@@ -73,8 +73,11 @@ def test_reference_sdf_test_volume(gpu_ctx, orc, sdf_golden):
     assert st["hits"] > 500
 
 
-def test_non_cubic_volume_and_wide_frame(gpu_ctx, orc):
-    vol, sdf, env, tf = small_scene(orc, 64, dims=(72, 40, 56))
+@pytest.mark.parametrize("dims", [(72, 40, 56), (96, 40, 56), (144, 24, 40)])
+def test_non_cubic_volume_and_wide_frame(gpu_ctx, orc, dims):
+    """rows of 72 voxels take k_repack's voxel-by-voxel staging; rows of 96 / 144 (a multiple of 16, not of the 64 voxels a block
+    repacks) its 16-byte staging in the first block(s) of a row and the other one in the last"""
+    vol, sdf, env, tf = small_scene(orc, 64, dims=dims)
     pos, d = look_at_centre(vol, [-30, 55, -20])
     _compare_passes(orc, gpu_ctx, vol, sdf, env, tf, (320, 64), pos, d, [11, 12])
 
