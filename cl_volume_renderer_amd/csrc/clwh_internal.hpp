@@ -153,8 +153,14 @@ hipError_t launch_repack(const RepackArgs &a, hipStream_t s);
 // few hundred KB, resident in every L2 -- at 2048^3 cells of 16^3 would make it 16 MiB and every look-up a miss of its own
 inline int macro_cell_shift(int X, int Y, int Z, int forced) {
   if (forced >= 3 && forced <= 8) return forced;  // CLWH_TUNE_MACRO_SHIFT (tests, experiments; 3: a cell is one brick)
+  // 16-voxel cells while the table stays L2-sized (512^3: 33^3 cells x 8 octants = 0.3 MB); beyond that 32-voxel cells up to 2048^3 (65^3
+  // cells, 2.2 MB: measured 28.3-28.5 ms per launch against 29.2-29.3 with 64-voxel cells and 29.2-30.2 with 16-voxel cells), then larger
+  auto cells = [&](int sh) { return (int64_t)((X >> sh) + 1) * ((Y >> sh) + 1) * ((Z >> sh) + 1); };
   int shift = 4;
-  while (shift < 8 && ((int64_t)((X >> shift) + 1) * ((Y >> shift) + 1) * ((Z >> shift) + 1)) > 40000) ++shift;
+  if (cells(4) > 40000) {
+    shift = 5;
+    while (shift < 8 && cells(shift) > 300000) ++shift;
+  }
   return shift;
 }
 hipError_t launch_macro_table(const uint32_t *brick_min, int NBX, int NBY, int NBZ, uint8_t *macro, int X, int Y, int Z, int shift, hipStream_t s);

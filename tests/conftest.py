@@ -97,7 +97,7 @@ def gpu_ctx_long():
 
 @pytest.fixture(scope="session")
 def gpu_ctx_long_big_cells():
-    """gpu_ctx_long with the exit certificates' macro cells forced to 64^3 voxels -- what a 2048^3 volume gets by itself"""
+    """gpu_ctx_long with the exit certificates' macro cells forced to 64^3 voxels -- what a volume beyond 2048^3 gets by itself (2048^3: 32^3, tests/test_gpu_fullsize.py)"""
     from cl_volume_renderer_amd import ffi
 
     os.environ["CLWH_TUNE_LONG_LAUNCH"] = "1"
