@@ -134,14 +134,18 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
   __syncthreads();
   const unsigned wave = tid >> 6, lane = tid & 63u;
   const size_t brick_row = ((size_t)blockIdx.z * (size_t)a.NBY + (size_t)blockIdx.y) * (size_t)a.NBX;
-  for (unsigned sb = wave; sb < (unsigned)kRepackX; sb += 4u) {  // kRepackX / 8 bricks x 8 sub-bricks
-    const unsigned bq = sb >> 3, sub = sb & 7u;
+  // A wave writes the sub-bricks `wave` and `wave + 4` of the block's bricks: the lane's place inside the sub-brick is worked out twice, not
+  // once per brick, and the rule table is walked without a per-lane `break` (a divergent loop exit costs more than the two rules it skips).
+  for (unsigned half = 0u; half < 2u; ++half) {
+   const unsigned sub = wave + 4u * half;
+   unsigned ix, iy, iz;
+   VolumePacked::inner_coords(sub * 64u + lane, ix, iy, iz);
+   const int ly = (int)iy, lz = (int)iz, y = y0 + ly, z = z0 + lz;
+   for (unsigned bq = 0u; bq < (unsigned)(kRepackX / 8); ++bq) {
     const int bx = (int)blockIdx.x * (kRepackX / 8) + (int)bq;
-    if (bx >= a.NBX) continue;
-    unsigned ix, iy, iz;
-    VolumePacked::inner_coords(sub * 64u + lane, ix, iy, iz);
-    const int lx = (int)(bq * 8u + ix), ly = (int)iy, lz = (int)iz;
-    const int x = x0 + lx, y = y0 + ly, z = z0 + lz;
+    if (bx >= a.NBX) break;
+    const int lx = (int)(bq * 8u + ix);
+    const int x = x0 + lx;
     uint2 r = uint2{0u, 0u};
     uint8_t q = 0u;
     bool record_read = false;  // can a march ever read this voxel's hit record?
@@ -163,14 +167,15 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
       unsigned cls = a.cls_in ? a.cls_in[((size_t)z * (size_t)a.Y + (size_t)y) * (size_t)a.X + (size_t)x] : 0u;
       // `maybe`: could this voxel be an event for SOME gradient?  (A rule that reads `gradient` is evaluated literally, with
       // other taps, at the rare positions whose +-1 taps are not the voxel's neighbours: its value window alone decides here.)
-      bool maybe = cls != 0u;
-      for (int k = 0; k < a.tf.n && !a.cls_in; ++k) {
+      bool maybe = cls != 0u, decided = a.cls_in != nullptr;
+      for (int k = 0; k < a.tf.n; ++k) {  // (wave-uniform trip count; `decided` lanes only ride along)
         const TfRuleDev &rule = a.tf.rules[k];
-        bool m = value >= rule.v_lo && value <= rule.v_hi;
-        maybe = maybe || m;
+        const bool in_window = value >= rule.v_lo && value <= rule.v_hi;
+        bool m = in_window;
         if (rule.flags & TF_USE_GRADIENT) m = m && gradient >= rule.g_lo && gradient <= rule.g_hi;
-        if (m && cls == 0u) cls = (unsigned)k + 1u;
-        if (m || (rule.flags & TF_TERMINAL)) break;
+        maybe = maybe || (!decided && in_window);
+        if (!decided && m && cls == 0u) cls = (unsigned)k + 1u;
+        decided = decided || m || (rule.flags & TF_TERMINAL) != 0;
       }
       r = VolumePacked::pack_hit(dx, dy, dz, cls);
       q = (uint8_t)((cls ? 0x80u : 0u) | (uint32_t)(sd > 0 ? sd : 0));
@@ -186,6 +191,7 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
     a.stepb[out] = q;
     for (int off = 32; off > 0; off >>= 1) free_min = min(free_min, (uint32_t)__shfl_xor((int)free_min, off));
     if (lane == 0u) atomicMin(&a.brick_min[brick_row + (size_t)bx], free_min);  // eight sub-bricks per brick
+   }
   }
 }
 
