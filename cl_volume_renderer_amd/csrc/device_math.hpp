@@ -80,4 +80,30 @@ __device__ __forceinline__ uint32_t hash_u32(uint32_t seed) {
   return seed;
 }
 
+// the smallest value of the wave (the same in every lane): four DPP steps inside the rows of 16 lanes (pairs and quads by quad permutes,
+// eights by the half-row mirror, sixteens by the row mirror -- every source lane exists), then the four rows through scalar registers; six
+// __shfl_xor steps are six LDS permutes with their address arithmetic.  Checked against that loop by clwh_debug_wave_min.
+template <int CTRL>
+__device__ __forceinline__ uint32_t wave_min_dpp_step(uint32_t t) {
+  const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp((int)t, (int)t, CTRL, 0xF, 0xF, false);
+  return other < t ? other : t;
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  uint32_t t = wave_min_dpp_step<0xB1>(v);  // quad_perm [1,0,3,2]
+  t = wave_min_dpp_step<0x4E>(t);           // quad_perm [2,3,0,1]
+  t = wave_min_dpp_step<0x141>(t);          // row_half_mirror
+  t = wave_min_dpp_step<0x140>(t);          // row_mirror
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)t, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)t, 16),
+                 r2 = (uint32_t)__builtin_amdgcn_readlane((int)t, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)t, 48);
+  const uint32_t a = r0 < r1 ? r0 : r1, b = r2 < r3 ? r2 : r3;
+  return a < b ? a : b;
+}
+__device__ __forceinline__ uint32_t wave_min_u32_reference(uint32_t v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)v, off);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
 }  // namespace clvr

@@ -65,6 +65,13 @@ __global__ __launch_bounds__(256) void k_debug_conversions(const float *__restri
   ou[i] = f2u(v); ou[n + i] = f2u_reference(v);
 }
 
+// one wave per 64 inputs: [0, n / 64) the DPP minimum (device_math.hpp), [n / 64, 2 n / 64) the shuffle loop
+__global__ __launch_bounds__(64) void k_debug_wave_min(const uint32_t *__restrict__ in, uint64_t n_waves, uint32_t *__restrict__ out) {
+  const uint32_t v = in[(uint64_t)blockIdx.x * 64u + threadIdx.x];
+  const uint32_t a = wave_min_u32(v), b = wave_min_u32_reference(v);
+  if (threadIdx.x == (blockIdx.x & 63u)) { out[blockIdx.x] = a; out[n_waves + blockIdx.x] = b; }  // (read from a different lane each time)
+}
+
 hipError_t sort_entry_pairs(void *temp, size_t &temp_bytes, const int64_t *keys_in, int64_t *keys_out, const uint32_t *vals_in,
                             uint32_t *vals_out, size_t n, unsigned end_bit, hipStream_t s) {
   return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, end_bit, s);
@@ -89,6 +96,16 @@ int clwh_debug_float_conversions(clwh_ctx *ctx, clwh_mem *floats_in, uint64_t n,
   HIP_TRY_X(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(k_debug_conversions, dim3((unsigned)((n + 255u) / 256u)), dim3(256), 0, ctx->stream, (const float *)floats_in->dptr, n,
                      (int32_t *)i32_out->dptr, (uint32_t *)u32_out->dptr);
+  HIP_TRY_X(hipGetLastError());
+  return CLWH_OK;
+}
+
+int clwh_debug_wave_min(clwh_ctx *ctx, clwh_mem *u32_in, uint64_t n, clwh_mem *u32_out) {
+  if (!ctx || !u32_in || !u32_out) return CLWH_ERR_INVALID_VALUE;
+  if ((n & 63u) != 0 || u32_in->bytes < n * 4 || u32_out->bytes < (n / 64) * 8 || n >= (1ull << 37)) return CLWH_ERR_SIZE_MISMATCH;
+  if (n == 0) return CLWH_OK;
+  HIP_TRY_X(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_debug_wave_min, dim3((unsigned)(n / 64)), dim3(64), 0, ctx->stream, (const uint32_t *)u32_in->dptr, n / 64, (uint32_t *)u32_out->dptr);
   HIP_TRY_X(hipGetLastError());
   return CLWH_OK;
 }

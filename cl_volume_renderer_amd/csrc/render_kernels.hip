@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_repack(const RepackArgs a) {
     // kernel wrote (8 of 12 bytes per voxel) was never read.
     if (__ballot(record_read) != 0ull) a.grec[out] = r;
     a.stepb[out] = q;
-    for (int off = 32; off > 0; off >>= 1) free_min = min(free_min, (uint32_t)__shfl_xor((int)free_min, off));
+    free_min = wave_min_u32(free_min);
     if (lane == 0u) atomicMin(&a.brick_min[brick_row + (size_t)bx], free_min);  // eight sub-bricks per brick
    }
   }

@@ -116,6 +116,7 @@ _PROTOTYPES = [
     ("clwh_cache_exchange_plan_release", C.c_int, [C.c_void_p]),
     ("clwh_tf_parse", C.c_int, [C.c_char_p, C.POINTER(Tf)]),
     ("clwh_debug_float_conversions", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
+    ("clwh_debug_wave_min", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     ("clwh_strerror", C.c_char_p, [C.c_int]),
     ("clwh_last_hip_error", C.c_int, []),
     ("clwh_version", C.c_char_p, []),

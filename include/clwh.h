@@ -282,6 +282,9 @@ int clwh_tf_parse(const char *source, clwh_tf *out);
  * perform with single hardware instructions: converts n floats on the device both ways -- the instruction and the definition
  * written out -- into int32 / uint32 arrays of 2 n elements each ([0, n): instruction, [n, 2n): definition) */
 int clwh_debug_float_conversions(clwh_ctx *ctx, clwh_mem *floats_in, uint64_t n, clwh_mem *i32_out, clwh_mem *u32_out);
+/* self-test of the wave-wide minimum k_repack takes over a sub-brick's 64 voxels for the exit-certificate table (cross-lane DPP
+ * operations): n (a multiple of 64) values, one wave per 64; u32_out[0, n/64) = that minimum, [n/64, 2n/64) = the same by a shuffle loop */
+int clwh_debug_wave_min(clwh_ctx *ctx, clwh_mem *u32_in, uint64_t n, clwh_mem *u32_out);
 const char *clwh_strerror(int status);
 int clwh_last_hip_error(void);
 const char *clwh_version(void);

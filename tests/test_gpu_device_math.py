@@ -54,3 +54,26 @@ def test_conversion_instructions_equal_their_definition(gpu_ctx):
         assert np.array_equal(gu[:n], _host_f2u(v))
     for m in (m_in, m_i, m_u):
         m.release()
+
+
+def test_wave_minimum_by_dpp_equals_the_shuffle_loop_and_numpy(gpu_ctx):
+    """k_repack's minimum over a sub-brick's 64 voxels (the exit-certificate table's input) is taken with cross-lane DPP operations:
+    the minimum in every lane position, ties, the values the kernel meets (0..127, 255) and arbitrary 32-bit patterns"""
+    rng = np.random.default_rng(5)
+    blocks = [rng.integers(0, 2 ** 32, (4096, 64), dtype=np.uint64).astype(np.uint32),
+              rng.choice(np.array(list(range(128)) + [255], np.uint32), (4096, 64)),
+              np.full((64, 64), 255, np.uint32)]
+    for lane in range(64):   # a single small value at every lane position
+        blocks[2][lane, lane] = lane
+    ties = np.full((64, 64), 7, np.uint32)
+    ties[:, ::3] = 3
+    v = np.concatenate(blocks + [ties, np.zeros((1, 64), np.uint32), np.full((1, 64), 0xFFFFFFFF, np.uint32)])
+    n_waves = v.shape[0]
+    m_in = gpu_ctx.buffer_from(v.reshape(-1))
+    m_out = gpu_ctx.buffer(n_waves * 8, np.uint32)
+    ffi._check(ffi.lib().clwh_debug_wave_min(gpu_ctx.h, m_in.h, C.c_uint64(v.size), m_out.h), "clwh_debug_wave_min")
+    gpu_ctx.finish()
+    got = m_out.pull()
+    want = v.min(axis=1)
+    assert np.array_equal(got[:n_waves], want) and np.array_equal(got[n_waves:], want)
+    m_in.release(); m_out.release()
