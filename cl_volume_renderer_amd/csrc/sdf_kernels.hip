@@ -541,13 +541,9 @@ struct SdfBitTiles {
 };
 
 // non-homogeneous voxels (create_base_image: some clamped corner neighbour's event flag differs) = the seeds R_0
-__global__ __launch_bounds__(256) void k_sdfbit_seed(const uint32_t *__restrict__ ev, uint32_t *__restrict__ r0, int32_t X, int32_t Y,
-                                                      int32_t Z, int32_t WP, int32_t *presence, SdfBitTiles tiles) {
-  size_t rowi;
-  uint32_t unit;
-  if (!sdfbit_row_unit((uint32_t)WP, (size_t)Y * (size_t)Z, rowi, unit)) return;
-  const int w = (int)unit;
-  const int z = (int)(rowi / (size_t)Y), y = (int)(rowi - (size_t)z * (size_t)Y);
+__device__ __forceinline__ void sdfbit_seed_word(const uint32_t *__restrict__ ev, uint32_t *__restrict__ r0, int32_t X, int32_t Y, int32_t Z, int32_t WP,
+                                                 int32_t *presence, const SdfBitTiles &tiles, int w, int y, int z) {
+  const size_t rowi = (size_t)z * (size_t)Y + (size_t)y;
   const int x_lo = w * 32;
   uint32_t valid = 0u;
   if (x_lo < X) valid = (X - x_lo >= 32) ? 0xFFFFFFFFu : ((1u << (X - x_lo)) - 1u);
@@ -568,6 +564,23 @@ __global__ __launch_bounds__(256) void k_sdfbit_seed(const uint32_t *__restrict_
   differs &= valid;
   r0[tiles.word(w, y, z)] = differs;
   if (differs) presence[0] = 1;  // non-zero marker, plain store (see k_sdf_base_front)
+}
+__global__ __launch_bounds__(256) void k_sdfbit_seed(const uint32_t *__restrict__ ev, uint32_t *__restrict__ r0, int32_t X, int32_t Y,
+                                                      int32_t Z, int32_t WP, int32_t *presence, SdfBitTiles tiles) {
+  size_t rowi;
+  uint32_t unit;
+  if (!sdfbit_row_unit((uint32_t)WP, (size_t)Y * (size_t)Z, rowi, unit)) return;
+  const int z = (int)(rowi / (size_t)Y), y = (int)(rowi - (size_t)z * (size_t)Y);
+  sdfbit_seed_word(ev, r0, X, Y, Z, WP, presence, tiles, (int)unit, y, z);
+}
+// rows of a multiple of WPB words (16, 32 or 64 lanes along x): a block takes sixteen consecutive rows, so that every 128-byte line of the
+// tiled image is written whole by one block (see k_sdfbit_expand16_rows16)
+template <int WPB>
+__global__ __launch_bounds__(16 * WPB) void k_sdfbit_seed_rows16(const uint32_t *__restrict__ ev, uint32_t *__restrict__ r0, int32_t X, int32_t Y,
+                                                                 int32_t Z, int32_t WP, int32_t *presence, SdfBitTiles tiles) {
+  const int w = (int)blockIdx.x * WPB + (int)(threadIdx.x % (unsigned)WPB), y = (int)blockIdx.y * 16 + (int)(threadIdx.x / (unsigned)WPB);
+  if (y >= Y) return;
+  sdfbit_seed_word(ev, r0, X, Y, Z, WP, presence, tiles, w, y, (int)blockIdx.z);
 }
 
 // The values, once: bit planes of the layer index + the final reached set + the event bits -> one signed byte per voxel.
@@ -595,15 +608,10 @@ __global__ __launch_bounds__(256) void k_sdfbit_expand(const uint32_t *__restric
 }
 
 // the same, sixteen voxels (one 16-byte store) per lane: rows of a multiple of 16 voxels
-__global__ __launch_bounds__(256) void k_sdfbit_expand16(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ reached, const uint32_t *__restrict__ planes,
-                                                          size_t plane_words, int8_t *__restrict__ sdf, int32_t X, int32_t Y, int32_t Z, int32_t WP,
-                                                          int32_t max_iterations, SdfBitTiles tiles) {
-  size_t row;
-  uint32_t unit;
-  if (!sdfbit_row_unit((uint32_t)(X / 16), (size_t)Y * (size_t)Z, row, unit)) return;
+__device__ __forceinline__ void sdfbit_expand16_voxels(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ reached, const uint32_t *__restrict__ planes,
+                                                       size_t plane_words, int8_t *__restrict__ sdf, int32_t X, int32_t WP, int32_t max_iterations,
+                                                       const SdfBitTiles &tiles, int x0, int y, int z, size_t row) {
   const uint32_t b1 = 0x01010101u;
-  const int x0 = (int)unit * 16;
-  const int z = (int)(row / (size_t)Y), y = (int)(row - (size_t)z * (size_t)Y);
   const size_t tw = tiles.word(x0 >> 5, y, z);
   const uint32_t sh = (uint32_t)(x0 & 31);
   const uint32_t e16 = (ev[row * (size_t)WP + (size_t)(x0 >> 5)] >> sh) & 0xFFFFu, r16 = (reached[tw] >> sh) & 0xFFFFu;
@@ -627,6 +635,27 @@ __global__ __launch_bounds__(256) void k_sdfbit_expand16(const uint32_t *__restr
     out[q] = (val ^ bytes_ff(eb)) + eb;                                                                      // two's complement per byte where the voxel is an event
   }
   *reinterpret_cast<uint4 *>(sdf + row * (size_t)X + (size_t)x0) = uint4{out[0], out[1], out[2], out[3]};
+}
+__global__ __launch_bounds__(256) void k_sdfbit_expand16(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ reached, const uint32_t *__restrict__ planes,
+                                                          size_t plane_words, int8_t *__restrict__ sdf, int32_t X, int32_t Y, int32_t Z, int32_t WP,
+                                                          int32_t max_iterations, SdfBitTiles tiles) {
+  size_t row;
+  uint32_t unit;
+  if (!sdfbit_row_unit((uint32_t)(X / 16), (size_t)Y * (size_t)Z, row, unit)) return;
+  const int z = (int)(row / (size_t)Y), y = (int)(row - (size_t)z * (size_t)Y);
+  sdfbit_expand16_voxels(ev, reached, planes, plane_words, sdf, X, WP, max_iterations, tiles, (int)unit * 16, y, z, row);
+}
+// Rows of a multiple of 16 * UPB voxels (UPB = 32 or 64 lanes along x): a block takes UPB * 16 voxels of SIXTEEN consecutive rows -- the rows
+// whose words share a 128-byte line in the tiled bit images (a tile keeps its 48 rows' word pairs contiguous).  With one or two rows per
+// block eight consecutive blocks -- on eight XCDs -- each fetched every line of the planes: 32 GB read for 9 GB of bit images at 2048^3.
+template <int UPB>
+__global__ __launch_bounds__(16 * UPB) void k_sdfbit_expand16_rows16(const uint32_t *__restrict__ ev, const uint32_t *__restrict__ reached,
+                                                                     const uint32_t *__restrict__ planes, size_t plane_words, int8_t *__restrict__ sdf,
+                                                                     int32_t X, int32_t Y, int32_t Z, int32_t WP, int32_t max_iterations, SdfBitTiles tiles) {
+  const int u = (int)(threadIdx.x % (unsigned)UPB), r = (int)(threadIdx.x / (unsigned)UPB);
+  const int x0 = ((int)blockIdx.x * UPB + u) * 16, y = (int)blockIdx.y * 16 + r, z = (int)blockIdx.z;
+  if (y >= Y) return;  // (x0 < X: X is a multiple of 16 * UPB)
+  sdfbit_expand16_voxels(ev, reached, planes, plane_words, sdf, X, WP, max_iterations, tiles, x0, y, z, (size_t)z * (size_t)Y + (size_t)y);
 }
 
 // A barrier of k_sdfbit_layers: LDS only.  __syncthreads() also waits for the wave's outstanding GLOBAL stores and atomics (a release fence
@@ -1082,14 +1111,28 @@ hipError_t launch_sdfbit_events(const SdfArgs &a, uint32_t *ev, int32_t WP, hipS
 hipError_t launch_sdfbit_seed(const SdfBitArgs &a, hipStream_t s) {
   const size_t n_rows = (size_t)a.Y * (size_t)a.Z;
   const SdfBitTiles tiles{a.BX, a.BY, a.core_z};
-  hipLaunchKernelGGL(k_sdfbit_seed, sdfbit_row_grid((uint32_t)a.WP, n_rows), dim3(256), 0, s, a.ev, a.r_out, a.X, a.Y, a.Z, a.WP, a.presence, tiles);
+  const dim3 rows16((unsigned)a.WP, ((unsigned)a.Y + 15u) / 16u, (unsigned)a.Z);  // x: divided by WPB below
+  if ((a.WP % 64) == 0)
+    hipLaunchKernelGGL(k_sdfbit_seed_rows16<64>, dim3(rows16.x / 64u, rows16.y, rows16.z), dim3(1024), 0, s, a.ev, a.r_out, a.X, a.Y, a.Z, a.WP, a.presence, tiles);
+  else if ((a.WP % 32) == 0)
+    hipLaunchKernelGGL(k_sdfbit_seed_rows16<32>, dim3(rows16.x / 32u, rows16.y, rows16.z), dim3(512), 0, s, a.ev, a.r_out, a.X, a.Y, a.Z, a.WP, a.presence, tiles);
+  else if ((a.WP % 16) == 0)
+    hipLaunchKernelGGL(k_sdfbit_seed_rows16<16>, dim3(rows16.x / 16u, rows16.y, rows16.z), dim3(256), 0, s, a.ev, a.r_out, a.X, a.Y, a.Z, a.WP, a.presence, tiles);
+  else
+    hipLaunchKernelGGL(k_sdfbit_seed, sdfbit_row_grid((uint32_t)a.WP, n_rows), dim3(256), 0, s, a.ev, a.r_out, a.X, a.Y, a.Z, a.WP, a.presence, tiles);
   return hipGetLastError();
 }
 
 hipError_t launch_sdfbit_expand(const SdfBitArgs &a, const uint32_t *reached, int32_t max_iterations, hipStream_t s) {
   const size_t n_rows = (size_t)a.Y * (size_t)a.Z;
   const SdfBitTiles tiles{a.BX, a.BY, a.core_z};
-  if ((a.X % 16) == 0 && max_iterations >= 1) {
+  if ((a.X % 1024) == 0 && max_iterations >= 1) {
+    hipLaunchKernelGGL(k_sdfbit_expand16_rows16<64>, dim3((unsigned)(a.X / 1024), ((unsigned)a.Y + 15u) / 16u, (unsigned)a.Z), dim3(1024), 0, s, a.ev, reached,
+                       (const uint32_t *)a.planes, a.plane_words, a.sdf, a.X, a.Y, a.Z, a.WP, max_iterations, tiles);
+  } else if ((a.X % 512) == 0 && max_iterations >= 1) {
+    hipLaunchKernelGGL(k_sdfbit_expand16_rows16<32>, dim3((unsigned)(a.X / 512), ((unsigned)a.Y + 15u) / 16u, (unsigned)a.Z), dim3(512), 0, s, a.ev, reached,
+                       (const uint32_t *)a.planes, a.plane_words, a.sdf, a.X, a.Y, a.Z, a.WP, max_iterations, tiles);
+  } else if ((a.X % 16) == 0 && max_iterations >= 1) {
     hipLaunchKernelGGL(k_sdfbit_expand16, sdfbit_row_grid((uint32_t)(a.X / 16), n_rows), dim3(256), 0, s, a.ev, reached, (const uint32_t *)a.planes,
                        a.plane_words, a.sdf, a.X, a.Y, a.Z, a.WP, max_iterations, tiles);
   } else {
