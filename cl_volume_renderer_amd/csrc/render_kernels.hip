@@ -498,21 +498,22 @@ __device__ __forceinline__ bool certify_exit(const RenderArgs &a, f3 p, f3 d, in
   const unsigned cx = min((unsigned)(int)p.x >> a.macro_shift, (unsigned)a.MNX - 1u), cy = min((unsigned)(int)p.y >> a.macro_shift, (unsigned)a.MNY - 1u),
                  cz = min((unsigned)(int)p.z >> a.macro_shift, (unsigned)a.MNZ - 1u);
   const unsigned octant = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-  const int box_min = a.macro[((((size_t)cz * (size_t)a.MNY + (size_t)cy) * (size_t)a.MNX + (size_t)cx) << 3) | octant];
+  const int box_min = a.macro[(((cz * (unsigned)a.MNY + cy) * (unsigned)a.MNX + cx) << 3) | octant];  // (at most 2^22 entries)
   // One kind of position is outside the reasoning below: a coordinate that landed exactly ON the far face (== dimension: not exited,
   // utility_ray.cl:112-117) reads the border SDF 0 and advances 0.5 |d| per step; with a direction component too small to move that
   // coordinate (0.5 x 2^-10 is above half an ulp of every dimension below 2^13) the reference can crawl along the face and even run
-  // out of its 70 steps.  Such directions get no certificate and march literally; for all others the next step leaves (the + 5).
+  // out of its 70 steps.  Such directions get no certificate and march literally; for all others the next step leaves (the 5).
   const float dmin = fminf(fminf(fabsf(d.x), fabsf(d.y)), fabsf(d.z));
   const float dsum = d.x + d.y + d.z;  // NaN direction: the position turns NaN and never leaves
-  // Every step inside the box is max(sdf, 0.5) >= box_min long and the direction has unit length, so the march has passed the face it
-  // leaves through -- at distance t_exit = min over the axes of (face - p) / d along the ray -- after t_exit / box_min steps; + 5 covers the
-  // roundings of this bound (v_rcp: one ulp), those of the march, and the strictness of exited_volume.  (No component of d is zero here.)
-  const float tx = (d.x < 0.0f ? p.x : (float)a.X - p.x) * __builtin_amdgcn_rcpf(fabsf(d.x));
-  const float ty = (d.y < 0.0f ? p.y : (float)a.Y - p.y) * __builtin_amdgcn_rcpf(fabsf(d.y));
-  const float tz = (d.z < 0.0f ? p.z : (float)a.Z - p.z) * __builtin_amdgcn_rcpf(fabsf(d.z));
-  const float steps = fminf(fminf(tx, ty), tz) * __builtin_amdgcn_rcpf((float)box_min) + 5.0f;
-  return box_min != 0 && steps <= (float)budget && dmin >= 0.0009765625f && dsum == dsum;
+  // Every step inside the box is max(sdf, 0.5) >= box_min long and the direction has unit length, so after (budget - 5) steps the march has
+  // travelled T = (budget - 5) * box_min along the ray (an integer below 2^14: exact) and has passed the face of an axis as soon as
+  // T * |d_axis| >= its distance to that face -- one axis is enough; the 5 steps kept back cover the roundings of the march, of these three
+  // products, and the strictness of exited_volume.  (Round 3 first took the smallest (face - p) / d over the axes: three reciprocals,
+  // quarter-rate instructions, for the same decision.)
+  const float T = (float)((budget - 5) * box_min);
+  const float fx = d.x < 0.0f ? p.x : (float)a.X - p.x, fy = d.y < 0.0f ? p.y : (float)a.Y - p.y, fz = d.z < 0.0f ? p.z : (float)a.Z - p.z;
+  const bool leaves = T * fabsf(d.x) >= fx || T * fabsf(d.y) >= fy || T * fabsf(d.z) >= fz;
+  return box_min != 0 && budget > 5 && leaves && dmin >= 0.0009765625f && dsum == dsum;
 }
 
 #ifndef CLVR_BOUNCE_WAVES_PER_SIMD
