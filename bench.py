@@ -483,9 +483,12 @@ def main():
     # 2.12 -> 2.06 / 1.20 -> 1.11 / 0.76 -> 0.65 ms per job for 2 / 4 / 8 ranks with two jobs in flight on 1024 blocks each, and 0.60 ms
     # for 8 ranks with three jobs on 768 blocks each (tools/emulate_rank.py, profiles/r02_emulate_rank_grid_sweep.txt); the single-GPU
     # job is indifferent and keeps the library default.  Placement knobs, read when a context is created; results do not depend on them.
+    calibrate_lanes = args.frames_in_flight is None and world == 1
     if args.frames_in_flight is None:
-        # one GPU: 1 / 2 / 3 jobs in flight = 31.5 / 32.5 / 33.0 Gsamples/s on the headline job (profiles/r03_frame_lanes.txt; the derived
-        # scene data is shared, a lane costs its own accumulation / frame / hit buffers only); ranks of a multi-GPU job: see below
+        # one GPU: 1 / 2 / 3 jobs in flight = 31.5 / 32.5 / 33.0 Gsamples/s on the headline job early in round 3 (profiles/r03_frame_lanes.txt)
+        # and 33.1 / 35.6 / 34.4 with the final k_bounce -- which of two and three is ahead differs by build and by box (the derived scene data
+        # is shared, a lane costs its own accumulation / frame / hit buffers only), so a single GPU creates three lanes and the untimed
+        # warm-up picks two or three of them (below); ranks of a multi-GPU job: see below
         args.frames_in_flight = 3 if (world >= 6 or world == 1) else 2
     if world > 1 and args.frames_in_flight >= 2:
         os.environ.setdefault("CLWH_TUNE_BLOCKS", "1024" if args.frames_in_flight == 2 else "768")
@@ -516,6 +519,7 @@ def main():
     # SDF / env-map device memory (adopted with clwh_image_wrap, not copied)
     n_acc = ffi.accum_len(W, H, world)
     n_lanes = max(1, args.frames_in_flight)
+    lanes_in_use = [n_lanes]  # how many of the lanes the frame jobs alternate over (the warm-up may settle on fewer)
     lanes = []
     for li in range(n_lanes):
         if li == 0:
@@ -539,7 +543,7 @@ def main():
     torch.cuda.synchronize()
 
     # seeds: the glibc rand() stream the never-seeded reference draws from, one per pass, continuing over the jobs
-    n_jobs_max = WU + 1 + K * MAX_REGIONS + 64
+    n_jobs_max = WU + 1 + K * (MAX_REGIONS + 4) + 64
     seed_stream = scene.glibc_rand(min(n_jobs_max * SPP, 4_000_000))
 
     def job_seeds(j):
@@ -551,7 +555,7 @@ def main():
     def frame_job(j, pull=False, serial=False):
         """one step: camera -> primary hits -> SPP passes -> (gather) -> RGBA8 frame in HBM"""
         pos, cdir = view["pos"], view["dir"]
-        ln = lanes[0 if serial else j % n_lanes]
+        ln = lanes[0 if serial else j % lanes_in_use[0]]
         with torch.cuda.stream(ln["stream"]):
             ln["ctx"].invalidate_derived(scene=False, camera=True)  # the first frame after a camera move: k_primary runs
             ln["accum"].zero_()
@@ -591,6 +595,16 @@ def main():
     for _ in range(max(WU + 1, n_lanes)):  # warm-up jobs (every lane at least once: its work buffers get their final size)
         est.append(timed_region(job, 1))
         job += 1
+    lane_calibration = None
+    if calibrate_lanes and n_lanes == 3 and not args.single_region and min(est) < 0.03:  # (jobs of 100 ms and more gain nothing either way)
+        # still warm-up, untimed as far as the result goes: the same K-job region with two and with three jobs in flight, twice each
+        lane_calibration = {}
+        for cand in (2, 3, 2, 3):
+            lanes_in_use[0] = cand
+            t = timed_region(job, K) / K
+            job += K
+            lane_calibration[cand] = min(t, lane_calibration.get(cand, t))
+        lanes_in_use[0] = 2 if lane_calibration[2] < lane_calibration[3] else 3
     est_job = max_over_ranks([min(est)])[0]
     regions = 1 if args.single_region else max(1, min(MAX_REGIONS, int(math.ceil(MIN_TIMED_SECONDS / max(est_job * K, 1e-6)))))
     region_s = []
@@ -648,7 +662,10 @@ def main():
                 SPP, (SPP + S - 1) // S, S, "RCCL all-gather of the resolved RGBA8 tiles + " if world > 1 else ""),
             "accumulation": "image-space float4 per pixel, 8x8 tiles interleaved over ranks",
             "passes_per_launch": S,
-            "frames_in_flight": n_lanes,
+            "frames_in_flight": lanes_in_use[0],
+            "frames_in_flight_calibration": ({"what": "ms per job of one untimed warm-up region (best of two) with two / three frame jobs in flight; the "
+                                              "timed regions use the faster", "2": round(lane_calibration[2] * 1e3, 4),
+                                              "3": round(lane_calibration[3] * 1e3, 4)} if lane_calibration else None),
             "one_frame_at_a_time": {"steps": k_serial, "ms_per_step": round(max_over_ranks([serial_s])[0] * 1e3 / k_serial, 4),
                                     "note": "the same jobs strictly serial on one stream; the per-kernel durations of the roofline come from this region"},
             "timed": {"regions": regions, "steps_per_region": K, "seconds_median": round(elapsed, 6),
