@@ -519,14 +519,25 @@ def main():
     # SDF / env-map device memory (adopted with clwh_image_wrap, not copied)
     n_acc = ffi.accum_len(W, H, world)
     n_lanes = max(1, args.frames_in_flight)
-    lanes_in_use = [n_lanes]  # how many of the lanes the frame jobs alternate over (the warm-up may settle on fewer)
+    # One GPU, no --frames-in-flight given: besides the three lanes on the library's default grid, two lanes whose launches take HALF the
+    # persistent grid each (CLWH_TUNE_BLOCKS, read when a context is created; placement only): two such launches co-reside instead of
+    # queueing behind each other.  The untimed warm-up runs a region with each set and the timed regions use the fastest (below).
+    half_grid = [n_lanes, n_lanes + 1] if (calibrate_lanes and n_lanes == 3 and "CLWH_TUNE_BLOCKS" not in os.environ) else []
     lanes = []
-    for li in range(n_lanes):
+    for li in range(n_lanes + len(half_grid)):
         if li == 0:
             stream, lctx, lvol, lsdf, lenv, lframe, lkernel = torch.cuda.current_stream(), ctx, d_vol, d_sdf, d_env, d_frame, kernel
         else:
-            stream = torch.cuda.Stream()
-            lctx = ffi.Context(local_rank, stream=stream.cuda_stream)
+            # (the first half-grid lane shares torch's current stream with lane 0 -- they never run in the same region -- so that the pair is
+            # one job on the current stream and one on a side stream, like the first two default lanes)
+            stream = torch.cuda.current_stream() if (half_grid and li == half_grid[0]) else torch.cuda.Stream()
+            if li in half_grid:
+                os.environ["CLWH_TUNE_BLOCKS"] = "1024"
+            try:
+                lctx = ffi.Context(local_rank, stream=stream.cuda_stream)
+            finally:
+                if li in half_grid:
+                    del os.environ["CLWH_TUNE_BLOCKS"]
             lvol = lctx.image_wrap(d_vol.device_ptr, [N, N, N], 1, np.int16, (N, N, N))
             lsdf = lctx.image_wrap(d_sdf.device_ptr, [N, N, N], 1, np.int8, (N, N, N))
             lenv = lctx.image_wrap(d_env.device_ptr, [args.env[0], args.env[1]], 4, np.uint8, (args.env[1], args.env[0], 4))
@@ -541,9 +552,14 @@ def main():
                           m_accum=lctx.wrap(acc.data_ptr(), acc.numel() * 4), tiles=tl, tiles_all=tl_all,
                           m_tiles=lctx.wrap(tl.data_ptr(), tl.numel() * 4), m_tiles_all=lctx.wrap(tl_all.data_ptr(), tl_all.numel() * 4)))
     torch.cuda.synchronize()
+    lane_sets = {"%d x the default grid" % n_lanes: list(range(n_lanes))}
+    if half_grid:
+        lane_sets["2 x the default grid"] = [0, 1]
+        lane_sets["2 x half the grid"] = half_grid
+    active = list(range(n_lanes))  # the lanes the frame jobs alternate over
 
     # seeds: the glibc rand() stream the never-seeded reference draws from, one per pass, continuing over the jobs
-    n_jobs_max = WU + 1 + K * (MAX_REGIONS + 4) + 64
+    n_jobs_max = WU + 1 + K * (MAX_REGIONS + 6) + 96
     seed_stream = scene.glibc_rand(min(n_jobs_max * SPP, 4_000_000))
 
     def job_seeds(j):
@@ -555,7 +571,7 @@ def main():
     def frame_job(j, pull=False, serial=False):
         """one step: camera -> primary hits -> SPP passes -> (gather) -> RGBA8 frame in HBM"""
         pos, cdir = view["pos"], view["dir"]
-        ln = lanes[0 if serial else j % lanes_in_use[0]]
+        ln = lanes[0 if serial else active[j % len(active)]]
         with torch.cuda.stream(ln["stream"]):
             ln["ctx"].invalidate_derived(scene=False, camera=True)  # the first frame after a camera move: k_primary runs
             ln["accum"].zero_()
@@ -596,15 +612,20 @@ def main():
         est.append(timed_region(job, 1))
         job += 1
     lane_calibration = None
-    if calibrate_lanes and n_lanes == 3 and not args.single_region and min(est) < 0.03:  # (jobs of 100 ms and more gain nothing either way)
-        # still warm-up, untimed as far as the result goes: the same K-job region with two and with three jobs in flight, twice each
+    if len(lane_sets) > 1 and not args.single_region and min(est) < 0.03:  # (jobs of 100 ms and more gain nothing either way)
+        # still warm-up, untimed as far as the result goes: the same K-job region with each set of lanes, twice
         lane_calibration = {}
-        for cand in (2, 3, 2, 3):
-            lanes_in_use[0] = cand
+        for name in list(lane_sets) * 2:
+            active[:] = lane_sets[name]
+            if name not in lane_calibration:
+                timed_region(job, len(active))  # (every lane of the set once first)
+                job += len(active)
             t = timed_region(job, K) / K
             job += K
-            lane_calibration[cand] = min(t, lane_calibration.get(cand, t))
-        lanes_in_use[0] = 2 if lane_calibration[2] < lane_calibration[3] else 3
+            lane_calibration[name] = min(t, lane_calibration.get(name, t))
+        active[:] = lane_sets[min(lane_calibration, key=lane_calibration.get)]
+    else:
+        active[:] = list(range(n_lanes))
     est_job = max_over_ranks([min(est)])[0]
     regions = 1 if args.single_region else max(1, min(MAX_REGIONS, int(math.ceil(MIN_TIMED_SECONDS / max(est_job * K, 1e-6)))))
     region_s = []
@@ -662,10 +683,12 @@ def main():
                 SPP, (SPP + S - 1) // S, S, "RCCL all-gather of the resolved RGBA8 tiles + " if world > 1 else ""),
             "accumulation": "image-space float4 per pixel, 8x8 tiles interleaved over ranks",
             "passes_per_launch": S,
-            "frames_in_flight": lanes_in_use[0],
-            "frames_in_flight_calibration": ({"what": "ms per job of one untimed warm-up region (best of two) with two / three frame jobs in flight; the "
-                                              "timed regions use the faster", "2": round(lane_calibration[2] * 1e3, 4),
-                                              "3": round(lane_calibration[3] * 1e3, 4)} if lane_calibration else None),
+            "frames_in_flight": len(active),
+            "persistent_grid_per_launch": ("half of the library's default (CLWH_TUNE_BLOCKS=1024): two launches co-reside" if active and active[0] in half_grid
+                                           else os.environ.get("CLWH_TUNE_BLOCKS", "library default (2048 blocks)")),
+            "frames_in_flight_calibration": ({"what": "ms per job of an untimed warm-up region (best of two) with each set of frame lanes; the timed "
+                                              "regions use the fastest; the roofline's kernel durations come from single launches on the default grid",
+                                              **{k: round(v * 1e3, 4) for k, v in lane_calibration.items()}} if lane_calibration else None),
             "one_frame_at_a_time": {"steps": k_serial, "ms_per_step": round(max_over_ranks([serial_s])[0] * 1e3 / k_serial, 4),
                                     "note": "the same jobs strictly serial on one stream; the per-kernel durations of the roofline come from this region"},
             "timed": {"regions": regions, "steps_per_region": K, "seconds_median": round(elapsed, 6),
@@ -792,13 +815,15 @@ def main():
     # ---- the same job from a pose whose frame the volume fills (scene.close_camera): its own value and k_bounce roofline
     if world == 1 and not args.no_secondary and rank == 0:
         view["pos"], view["dir"] = scene.close_camera(N)
-        timed_region(job, n_lanes)  # every lane once: work buffers grow to this view's hit count
-        job += n_lanes
+        timed_region(job, len(active))  # every lane once: work buffers grow to this view's hit count
+        job += len(active)
         kf = max(2, min(K, 10))
         t_close = []
         while sum(t_close) < 0.3 and len(t_close) < 20:
             t_close.append(timed_region(job, kf))
             job += kf
+        timed_region(job, 1, serial=True)  # (lane 0 may not be among the lanes in use: its buffers meet this view here)
+        job += 1
         ctx.set_timing(True)
         timed_region(job, 2, serial=True)
         job += 2
@@ -831,7 +856,9 @@ def main():
     # ---- end to end incl. the final frame readback (SURVEY 8d metric ii); same jobs, frame pulled after each
     if not args.no_secondary:
         k2 = max(1, min(K, 10))
-        t = max_over_ranks([timed_region(job, k2, pull=True)])[0]
+        # (a blocking pull after every job leaves one job on the GPU at a time: on one GPU they run on lane 0, whose launches take the
+        # whole grid, whatever set of lanes the timed regions used)
+        t = max_over_ranks([timed_region(job, k2, pull=True, serial=(world == 1))])[0]
         job += k2
         if rank == 0:
             result["end_to_end"] = {
