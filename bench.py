@@ -626,6 +626,7 @@ def main():
         active[:] = lane_sets[min(lane_calibration, key=lane_calibration.get)]
     else:
         active[:] = list(range(n_lanes))
+    untimed_jobs = job  # warm-up jobs + the lane calibration's
     est_job = max_over_ranks([min(est)])[0]
     regions = 1 if args.single_region else max(1, min(MAX_REGIONS, int(math.ceil(MIN_TIMED_SECONDS / max(est_job * K, 1e-6)))))
     region_s = []
@@ -683,6 +684,7 @@ def main():
                 SPP, (SPP + S - 1) // S, S, "RCCL all-gather of the resolved RGBA8 tiles + " if world > 1 else ""),
             "accumulation": "image-space float4 per pixel, 8x8 tiles interleaved over ranks",
             "passes_per_launch": S,
+            "untimed_jobs_before_the_first_region": untimed_jobs,
             "frames_in_flight": len(active),
             "persistent_grid_per_launch": ("half of the library's default (CLWH_TUNE_BLOCKS=1024): two launches co-reside" if active and active[0] in half_grid
                                            else os.environ.get("CLWH_TUNE_BLOCKS", "library default (2048 blocks)")),
